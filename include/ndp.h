@@ -1,0 +1,204 @@
+/* ndp.h -- C ABI of libndp_hip.so: the MI355X (gfx950) implementation of the
+ * GAN-training hot path of goodmattg/ndivplanning.
+ *
+ * The reference has no FFI layer; its boundary for this path is Python
+ * (models/gan.py, diversity.py, train_gan.py).  The functions below are what a
+ * binding for that path calls (ctypes stub: INTEGRATION.md).  Each one names the
+ * reference code it replaces (paths relative to the reference checkout).
+ *
+ * Conventions (all functions):
+ *   - every pointer is a DEVICE pointer to contiguous row-major fp32 unless
+ *     stated otherwise; the caller owns every buffer, nothing is allocated or
+ *     freed inside, no call synchronises;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); work
+ *     is enqueued on it and the call returns immediately (graph-capturable);
+ *   - return value 0 = enqueued; non-zero = NDP_E_* and nothing was launched;
+ *     ndp_last_error() returns a thread-local message for the last failure;
+ *   - no global mutable state: calls from different host threads on different
+ *     streams are independent (autograd invokes backward from its own thread).
+ *
+ * Parameter vectors: the networks' parameters are ONE flat fp32 vector each, in
+ * state_dict order fc1.weight, fc1.bias, fc2.weight, ... (weight [out][in]
+ * row-major, as nn.Linear stores it).  Gradients and Adam moments use the same
+ * layout.  ndp_g_param_count / ndp_d_param_count give the lengths.
+ */
+#ifndef NDP_H_
+#define NDP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NDP_VERSION 100          /* 0.1.0 */
+
+#define NDP_OK            0
+#define NDP_E_ARG         1      /* bad argument (shape, alignment, null) */
+#define NDP_E_LAUNCH      2      /* hipLaunchKernel / hipMemsetAsync failed */
+#define NDP_E_UNSUPPORTED 3      /* valid request this build does not cover */
+
+#define NDP_CODE_DIM      256    /* cat(state_code, target_code): train_gan.py:155 */
+#define NDP_ACTION_DIM    4      /* models/gan.py:71,94 */
+#define NDP_MAX_NOISE_DIM 16
+#define NDP_MAX_SAMPLES   256    /* K, diversity samples per row */
+#define NDP_ROW_PAD       32     /* row counts of workspaces are padded to this */
+
+int         ndp_version(void);
+const char *ndp_last_error(void);
+
+/* Number of fp32 parameters of Decoder(noise_dim) (models/gan.py:61-71) and of
+ * Discriminator() (models/gan.py:89-97): 83,780 at noise_dim 2 and 58,305. */
+int64_t ndp_g_param_count(int noise_dim);
+int64_t ndp_d_param_count(void);
+
+/* rows rounded up to NDP_ROW_PAD */
+int64_t ndp_pad_rows(int64_t rows);
+
+/* ------------------------------------------------------------------ NDiv ---
+ * diversity.compute_pairwise_divergence(recodes=x, codes=z), forward and
+ * backward in one pass (diversity.py:8-19, 36-41):
+ *   loss = sum_{n,i,j} relu(0.8 * dz_ij/sum_j dz_ij - dx_ij/sum_j dx_ij)
+ * with the row sums treated as constants in the gradient (diversity.py:18) and
+ * a zero sub-gradient where dx_ij == 0 (torch.norm's backward).
+ *   x        [n, k, cx]   recodes (generated actions)
+ *   z        [n, k, cz]   codes (noise)
+ *   loss_out [1]          written (not accumulated)
+ *   grad_x   [n, k, cx]   d(grad_scale*loss)/dx, written; may be NULL
+ *   partials [ndp_ndiv_partials(n,k)] scratch
+ * 1 <= k <= NDP_MAX_SAMPLES, 1 <= cx,cz <= 16.  k == 1 yields NaN like the
+ * reference (0/0). */
+int64_t ndp_ndiv_partials(int64_t n, int k);
+int ndp_ndiv_fwd_bwd(const float *x, int cx, const float *z, int cz, int64_t n, int k,
+                     float grad_scale, float *loss_out, float *grad_x, float *partials,
+                     void *stream);
+
+/* ---------------------------------------------------------- Generator G ---
+ * Decoder.forward (models/gan.py:79-86): action_hat = fc5(relu(fc4(relu(fc3(
+ * relu(fc2(relu(fc1(cat[code, noise]))))))))).
+ * The input is given as its two parts so that the K-fold repeat of the code
+ * (train_gan.py:42-47) never has to be materialised:
+ *   code   row r of the network input uses code[(r / code_rep) * ld_code ...+256)
+ *   noise  row r uses noise[r * ld_noise ...+noise_dim)
+ * For a plain z [m, 256+nz] pass code=z, ld_code=256+nz, code_rep=1,
+ * noise=z+256, ld_noise=256+nz.
+ *   acts   NULL, or workspace of ndp_g_acts_floats(m) floats receiving the
+ *          hidden activations h1..h4 (needed by ndp_g_backward)
+ *   action_hat [m, 4] */
+int64_t ndp_g_acts_floats(int64_t m);
+int ndp_g_forward(const float *g_params, int noise_dim,
+                  const float *code, int64_t ld_code, int code_rep,
+                  const float *noise, int64_t ld_noise, int64_t m,
+                  float *acts, float *action_hat, void *stream);
+
+/* Backward of Decoder.forward for the parameters (what autograd computes at
+ * train_gan.py:202 for the Decoder): given d_action [m,4] = dLoss/d action_hat
+ * and the activations saved by ndp_g_forward, writes
+ *   grad [ndp_g_param_count]  dLoss/d params (written, not accumulated)
+ *   ws   scratch of ndp_g_bwd_ws_floats(m, noise_dim) floats
+ * No gradient is produced for the network input (the reference detaches the
+ * codes and never differentiates the noise: train_gan.py:152-153, 44). */
+int64_t ndp_g_bwd_ws_floats(int64_t m, int noise_dim);
+int ndp_g_backward(const float *g_params, int noise_dim,
+                   const float *code, int64_t ld_code, int code_rep,
+                   const float *noise, int64_t ld_noise, int64_t m,
+                   const float *acts, const float *d_action,
+                   float *grad, float *ws, void *stream);
+
+/* ------------------------------------------------------ Discriminator D ---
+ * Discriminator.forward (models/gan.py:104-110): logits = fc4(lrelu(fc3(lrelu(
+ * fc2(lrelu(fc1(cat[action, code]))))))), slope 0.01.
+ *   action row r uses action[(r / action_rep) * 4 ...+4)
+ *   code   row r uses code[(r / code_rep) * ld_code ...+256)
+ *   logits [m] */
+int ndp_d_forward(const float *d_params,
+                  const float *action, int action_rep,
+                  const float *code, int64_t ld_code, int code_rep, int64_t m,
+                  float *logits, void *stream);
+
+/* Backward of Discriminator.forward given d_logits [m] = dLoss/d logits
+ * (recomputes the forward inside the kernel; nothing needs to be saved):
+ *   grad     [ndp_d_param_count] or NULL   dLoss/d params (written)
+ *   d_action [m,4] or NULL                 dLoss/d action (written; needs action_rep==1)
+ *   ws       scratch of ndp_d_bwd_ws_floats(m) floats (only used when grad != NULL) */
+int64_t ndp_d_bwd_ws_floats(int64_t m);
+int ndp_d_backward(const float *d_params,
+                   const float *action, int action_rep,
+                   const float *code, int64_t ld_code, int code_rep, int64_t m,
+                   const float *d_logits, float *grad, float *d_action,
+                   float *ws, void *stream);
+
+/* ----------------------------------------------------------------- Adam ---
+ * torch.optim.Adam.step for one flat parameter vector (train_gan.py:98-104,
+ * 184, 203): m += (1-b1)(g-m); v = b2 v + (1-b2) g^2;
+ * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),  t = *step_count + 1.
+ * step_count is a DEVICE int32 that the call increments (after use), so that a
+ * captured graph replays with the right bias correction. */
+int ndp_adam_step(float *params, const float *grad, float *exp_avg, float *exp_avg_sq,
+                  int64_t n, int32_t *step_count, float lr, float beta1, float beta2,
+                  float eps, void *stream);
+
+/* ------------------------------------------------------ fused train step ---
+ * One iteration of the train_gan.py loop body (train_gan.py:159-203) on a local
+ * shard of `flat` rows (FLAT = batch*(traj_len-1)), each with K = num_sample
+ * diversity samples, M = flat*K rows through G and D.  The step is split where
+ * a data-parallel driver has to all-reduce gradients; single-GPU training sets
+ * fuse_adam = 1 and never sees the gradients.
+ *
+ *   phase A  ndp_step_d_grads : [first call of the step: G forward]
+ *            D(real), D(fake) forward, BCE, D backward  -> D gradient
+ *            (train_gan.py:165-183); with fuse_adam the D Adam update too (184)
+ *   phase B  ndp_step_g_grads : D(fake) forward with the UPDATED D, G loss,
+ *            NDiv loss + gradient, backward through D and G -> G gradient
+ *            (train_gan.py:187-202); with fuse_adam the G Adam update too (203)
+ *   ndp_adam_step              for the non-fused (data-parallel) case
+ *
+ * Scaling for data parallelism: BCE terms are means over
+ * the GLOBAL row count, so inv_m_global = 1/(M summed over ranks); the NDiv term
+ * is a sum and is not scaled.  Gradients of all ranks are then SUMMED.
+ */
+typedef struct ndp_step_config {
+  int32_t noise_dim;           /* training.gan.noise_dim  (1..16) */
+  int32_t num_sample;          /* training.gan.num_sample (1..256) */
+  int64_t flat;                /* local FLAT rows */
+  float   inv_m_global;        /* 1 / global M */
+  float   pairwise_div_factor; /* training.gan.pairwise_div_factor */
+  float   lr, beta1, beta2, eps;
+  int32_t fuse_adam;           /* 1: apply Adam inside the phase; 0: leave grads */
+  int32_t reserved;
+} ndp_step_config;
+
+/* Caller-owned persistent state of one trainer (all device memory). */
+typedef struct ndp_step_buffers {
+  float   *g_params, *g_grad, *g_exp_avg, *g_exp_avg_sq;   /* [ndp_g_param_count] */
+  float   *d_params, *d_grad, *d_exp_avg, *d_exp_avg_sq;   /* [ndp_d_param_count] */
+  int32_t *g_step, *d_step;                                 /* Adam step counts */
+  float   *losses;       /* [4]: D_loss, G_loss, pair_div (local shares), unused */
+  float   *loss_sums;    /* [4]: running sums of the above (epoch averages) or NULL */
+  float   *action_hat;   /* [pad(M), 4] generated actions of the current step */
+  float   *workspace;    /* ndp_step_workspace_floats(cfg) floats */
+} ndp_step_buffers;
+
+int64_t ndp_step_workspace_floats(const ndp_step_config *cfg);
+
+/* codes [flat,256], actions [flat,4] (ground truth), noise [flat,K,nz].
+ * run_g_forward: 1 on the first D step of an iteration, 0 on repeats
+ * (discrim_steps_per_gen > 1 re-uses action_hat, train_gan.py:172). */
+int ndp_step_d_grads(const ndp_step_config *cfg, const ndp_step_buffers *buf,
+                     const float *codes, const float *actions, const float *noise,
+                     int run_g_forward, void *stream);
+int ndp_step_g_grads(const ndp_step_config *cfg, const ndp_step_buffers *buf,
+                     const float *codes, const float *actions, const float *noise,
+                     void *stream);
+
+/* Device-side uniform noise U[0,1) for diverse_sampling (train_gan.py:44) when
+ * the caller does not need the reference's CPU random stream: counter-based
+ * (Philox-4x32-10), element i of call `offset` depends only on (seed, offset, i). */
+int ndp_uniform_noise(float *out, int64_t n, uint64_t seed, const int32_t *offset_dev,
+                      void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NDP_H_ */

@@ -1,0 +1,136 @@
+"""ctypes binding of libndp_hip.so (include/ndp.h) + tensor-level call helpers.
+
+This is the only place that touches the shared library.  Loading fails loudly
+(ImportError-like RuntimeError) when the library is missing: the product has no
+CPU or PyTorch-eager fallback.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
+
+import torch
+
+from . import _build
+
+CODE_DIM = 256
+ACTION_DIM = 4
+MAX_NOISE_DIM = 16
+MAX_SAMPLES = 256
+ROW_PAD = 32
+
+_lib = None
+
+
+class NdpError(RuntimeError):
+    pass
+
+
+class StepConfig(Structure):
+    """struct ndp_step_config (include/ndp.h)."""
+    _fields_ = [("noise_dim", c_int32), ("num_sample", c_int32), ("flat", c_int64),
+                ("inv_m_global", c_float), ("pairwise_div_factor", c_float),
+                ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
+                ("fuse_adam", c_int32), ("reserved", c_int32)]
+
+
+class StepBuffers(Structure):
+    """struct ndp_step_buffers (include/ndp.h)."""
+    _fields_ = [(n, c_void_p) for n in (
+        "g_params", "g_grad", "g_exp_avg", "g_exp_avg_sq",
+        "d_params", "d_grad", "d_exp_avg", "d_exp_avg_sq",
+        "g_step", "d_step", "losses", "loss_sums", "action_hat", "workspace")]
+
+
+# name -> (restype, argtypes); the symbol list tests/test_capi_symbols.py checks against ndp.h
+SIGNATURES = {
+    "ndp_version": (c_int, []),
+    "ndp_last_error": (c_char_p, []),
+    "ndp_g_param_count": (c_int64, [c_int]),
+    "ndp_d_param_count": (c_int64, []),
+    "ndp_pad_rows": (c_int64, [c_int64]),
+    "ndp_ndiv_partials": (c_int64, [c_int64, c_int]),
+    "ndp_ndiv_fwd_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_float,
+                                 c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ndp_g_acts_floats": (c_int64, [c_int64]),
+    "ndp_g_forward": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64,
+                              c_void_p, c_void_p, c_void_p]),
+    "ndp_g_bwd_ws_floats": (c_int64, [c_int64, c_int]),
+    "ndp_g_backward": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ndp_d_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
+    "ndp_d_bwd_ws_floats": (c_int64, [c_int64]),
+    "ndp_d_backward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int64, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ndp_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                              c_float, c_float, c_float, c_float, c_void_p]),
+    "ndp_step_workspace_floats": (c_int64, [POINTER(StepConfig)]),
+    "ndp_step_d_grads": (c_int, [POINTER(StepConfig), POINTER(StepBuffers), c_void_p, c_void_p, c_void_p,
+                                 c_int, c_void_p]),
+    "ndp_step_g_grads": (c_int, [POINTER(StepConfig), POINTER(StepBuffers), c_void_p, c_void_p, c_void_p,
+                                 c_void_p]),
+    "ndp_uniform_noise": (c_int, [c_void_p, c_int64, c_uint64, c_void_p, c_void_p]),
+}
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load libndp_hip.so and declare every prototype.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise NdpError(
+            "ndivplanning_amd: %s is missing -- build it with `python -m ndivplanning_amd._build` "
+            "(or __graft_entry__.build()); there is no fallback path." % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().ndp_last_error()
+        raise NdpError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def require_gpu_f32(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise NdpError("%s is on %s: ndivplanning_amd computes only on a ROCm GPU (no CPU fallback)"
+                       % (name, t.device))
+    if t.dtype != torch.float32:
+        raise NdpError("%s must be float32, got %s" % (name, t.dtype))
+    return t
+
+
+def empty(n, like):
+    return torch.empty(int(n), dtype=torch.float32, device=like.device)
+
+
+def g_param_count(noise_dim):
+    return int(load().ndp_g_param_count(int(noise_dim)))
+
+
+def d_param_count():
+    return int(load().ndp_d_param_count())
+
+
+def pad_rows(m):
+    return (int(m) + ROW_PAD - 1) // ROW_PAD * ROW_PAD

@@ -1,0 +1,336 @@
+// ndp_device.h -- gfx950 (CDNA4) device building blocks for the fused MLP kernels.
+//
+// Everything is exact fp32: the matrix work runs on v_mfma_f32_16x16x4_f32 (f32 in,
+// f32 accumulate, bitwise an fmaf chain -- cdna_hip_programming.md section 3), there is
+// no reduced-precision path.
+//
+// Tiling model (one workgroup = 4 waves = 256 threads = one tile of R = 16*RT rows):
+//   * the row tile's activations live in LDS, row-major with stride ld = width + 4
+//     floats (ld = 4 mod 32: conflict-free C-layout ds_write_b32, one 2-way slot per
+//     ds_read_b128 group);
+//   * a layer's weights are read ONCE per workgroup, straight from global/L2 into the
+//     MFMA B operand registers: every weight element is needed by exactly one wave
+//     (wave w owns output columns), so staging them through LDS would only add a round
+//     trip.  Both the forward (reduce over W's row = contiguous dim) and the data
+//     gradient (reduce over W's column) read W in its native nn.Linear [out][in]
+//     layout with 8/16-byte vector loads, by permuting the reduction index (forward)
+//     or the output column index (dgrad) among lanes -- a sum does not care about order.
+//
+// MFMA 16x16x4 f32 operand maps (lane l: c = l & 15, q = l >> 4):
+//   A[i = c][k = q], B[k = q][j = c], C/D: col j = c, rows i = 4q + reg (reg 0..3).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ndp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr float kLreluSlope = 0.01f;   // F.leaky_relu default (models/gan.py:106-108)
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
+
+__device__ __forceinline__ int lds_ld(int width) { return width + 4; }
+
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float v) {
+  if (ACT == ACT_RELU) return v > 0.f ? v : 0.f;
+  if (ACT == ACT_LRELU) return v > 0.f ? v : v * kLreluSlope;
+  return v;
+}
+
+// derivative taken from the POST-activation value h (sign-preserving activations):
+// relu: threshold_backward passes g where x > 0; lrelu: g where x > 0 else slope*g.
+template <int ACT>
+__device__ __forceinline__ float act_bwd(float h, float g) {
+  if (ACT == ACT_RELU) return h > 0.f ? g : 0.f;
+  if (ACT == ACT_LRELU) return h > 0.f ? g : g * kLreluSlope;
+  return g;
+}
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+template <int WALIGN>
+__device__ __forceinline__ f32x4 ldg4(const float* p) {
+  if (WALIGN >= 4) {
+    return *reinterpret_cast<const f32x4*>(p);
+  } else {
+    f32x2 lo = *reinterpret_cast<const f32x2*>(p);
+    f32x2 hi = *reinterpret_cast<const f32x2*>(p + 2);
+    f32x4 r = {lo[0], lo[1], hi[0], hi[1]};
+    return r;
+  }
+}
+
+// ----------------------------------------------------------------------------------
+// Y[R x OUT] = act( X[R x IN] . Wm^T  (+ Xt[R x tail_n] . Wt^T)  + bias )
+//   X, Xt, Y in LDS; Wm/Wt rows are rows of one nn.Linear weight (row stride ldw).
+//   IN % 16 == 0, OUT % 64 == 0.  Wave w owns columns [w*OUT/4, (w+1)*OUT/4).
+//   Lane (q,c) loads 4 consecutive reduction indices k = 16t + 4q .. +3 of its weight
+//   row and of its activation row; MFMA step s pairs element s of both, so the four
+//   lane groups cover k = 16t + {s, 4+s, 8+s, 12+s}: a permutation of the k order.
+//   WALIGN: 4 if (Wm + j*ldw) is 16-byte aligned for every j, else 2 (8-byte).
+// Caller synchronises before (X ready) and after (Y ready).
+template <int RT, int IN, int OUT, int ACT, int WALIGN>
+__device__ __forceinline__ void layer_fwd(const float* X, int ldx,
+                                          const float* __restrict__ Wm, int ldw,
+                                          const float* __restrict__ bias,
+                                          float* Y, int ldy,
+                                          const float* Xt, int ldt, int tail_n,
+                                          const float* __restrict__ Wt) {
+  static_assert(IN % 16 == 0 && OUT % 64 == 0, "layer_fwd shape");
+  constexpr int NT = OUT / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+
+  f32x4 acc[RT][NT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[r][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int col0 = wave * (OUT / 4);
+  const float* wp = Wm + (size_t)(col0 + c) * ldw + 4 * q;
+  const float* xp = X + c * ldx + 4 * q;
+
+#pragma unroll
+  for (int k0 = 0; k0 < IN; k0 += 16) {
+    f32x4 bv[NT], av[RT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bv[n] = ldg4<WALIGN>(wp + (size_t)(n * 16) * ldw + k0);
+#pragma unroll
+    for (int r = 0; r < RT; ++r) av[r] = *reinterpret_cast<const f32x4*>(xp + r * 16 * ldx + k0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[r][n] = mfma16(av[r][s], bv[n][s], acc[r][n]);
+  }
+
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int col = col0 + n * 16 + c;
+    const float b = bias[col];
+    float wt[16];
+    if (Xt != nullptr) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) wt[t] = t < tail_n ? Wt[(size_t)col * ldw + t] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = r * 16 + 4 * q + i;
+        float v = acc[r][n][i] + b;
+        if (Xt != nullptr) {
+          for (int t = 0; t < tail_n; ++t) v = fmaf(Xt[row * ldt + t], wt[t], v);
+        }
+        Y[row * ldy + col] = act_fwd<ACT>(v);
+      }
+  }
+}
+
+// ----------------------------------------------------------------------------------
+// In place: H[R x IN] <- act'(H) * ( dY[R x OUT] . W[OUT x IN] )
+//   dY, H in LDS; W = nn.Linear weight [OUT][ldw] whose layer maps IN -> OUT.
+//   IN in {64, 128}: wave w owns the 16*V columns [w*16V, (w+1)*16V), V = IN/64; lane c
+//   holds columns V*c .. V*c+V-1 of that group (one V-wide vector load per weight row),
+//   i.e. MFMA column tile v consists of columns {V*c + v}.  Reduction index j = 16t+4q+s
+//   pairs element s of the lane's dY vector with weight row j.
+template <int RT, int IN, int OUT, int ACT>
+__device__ __forceinline__ void layer_dgrad(const float* dY, int ldd,
+                                            const float* __restrict__ W, int ldw,
+                                            float* H, int ldh) {
+  static_assert((IN == 64 || IN == 128) && OUT % 16 == 0, "layer_dgrad shape");
+  constexpr int V = IN / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+
+  f32x4 acc[RT][V];
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[r][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int colbase = wave * 16 * V + V * c;
+  const float* wp = W + (size_t)(4 * q) * ldw + colbase;
+  const float* dp = dY + c * ldd + 4 * q;
+
+#pragma unroll
+  for (int j0 = 0; j0 < OUT; j0 += 16) {
+    float bv[4][V];
+    f32x4 av[RT];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float* p = wp + (size_t)(j0 + s) * ldw;
+      if (V == 2) {
+        f32x2 t = *reinterpret_cast<const f32x2*>(p);
+        bv[s][0] = t[0];
+        bv[s][V - 1] = t[1];
+      } else {
+        bv[s][0] = *p;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) av[r] = *reinterpret_cast<const f32x4*>(dp + r * 16 * ldd + j0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[r][v] = mfma16(av[r][s], bv[s][v], acc[r][v]);
+  }
+
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float* hp = H + (r * 16 + 4 * q + i) * ldh + colbase;
+#pragma unroll
+      for (int v = 0; v < V; ++v) hp[v] = act_bwd<ACT>(hp[v], acc[r][v][i]);
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// Narrow output layers on the VALU: Y[R x OUT] = X[R x IN] . W^T + bias, OUT in {1, 4}.
+//   256 threads = R rows x PARTS parts; a part takes every PARTS-th float4 of the row.
+//   Result written to Yout (LDS, row stride ldy) by the part-0 lane of each row.
+template <int RT, int IN, int OUT>
+__device__ __forceinline__ void layer_fwd_narrow(const float* X, int ldx,
+                                                 const float* __restrict__ W,
+                                                 const float* __restrict__ bias,
+                                                 float* Y, int ldy) {
+  constexpr int R = 16 * RT;
+  constexpr int PARTS = kThreads / R;           // 16 (RT=1) or 8 (RT=2)
+  constexpr int NV = IN / 4 / PARTS;            // float4s per part
+  static_assert(IN % (4 * PARTS) == 0, "layer_fwd_narrow shape");
+  const int row = threadIdx.x / PARTS, part = threadIdx.x % PARTS;
+  float sum[OUT];
+#pragma unroll
+  for (int o = 0; o < OUT; ++o) sum[o] = 0.f;
+#pragma unroll
+  for (int m = 0; m < NV; ++m) {
+    const int k = 4 * (part + PARTS * m);
+    const f32x4 x = *reinterpret_cast<const f32x4*>(X + row * ldx + k);
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(W + (size_t)o * IN + k);
+      sum[o] = fmaf(x[0], w[0], sum[o]);
+      sum[o] = fmaf(x[1], w[1], sum[o]);
+      sum[o] = fmaf(x[2], w[2], sum[o]);
+      sum[o] = fmaf(x[3], w[3], sum[o]);
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < OUT; ++o) {
+#pragma unroll
+    for (int d = PARTS / 2; d >= 1; d >>= 1) sum[o] += __shfl_xor(sum[o], d, 64);
+  }
+  if (part == 0) {
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) Y[row * ldy + o] = sum[o] + bias[o];
+  }
+}
+
+// In place: H[R x IN] <- act'(H) * ( dY[R x OUT] . W[OUT x IN] ), OUT in {1, 4} (VALU).
+template <int RT, int IN, int OUT, int ACT>
+__device__ __forceinline__ void layer_dgrad_narrow(const float* dY, int ldd,
+                                                   const float* __restrict__ W,
+                                                   float* H, int ldh) {
+  constexpr int R = 16 * RT;
+  constexpr int NV = R * IN / 4;
+  for (int idx = threadIdx.x; idx < NV; idx += kThreads) {
+    const int row = idx / (IN / 4), k = 4 * (idx % (IN / 4));
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) {
+      const float d = dY[row * ldd + o];
+      const f32x4 w = *reinterpret_cast<const f32x4*>(W + (size_t)o * IN + k);
+      g[0] = fmaf(d, w[0], g[0]);
+      g[1] = fmaf(d, w[1], g[1]);
+      g[2] = fmaf(d, w[2], g[2]);
+      g[3] = fmaf(d, w[3], g[3]);
+    }
+    f32x4* hp = reinterpret_cast<f32x4*>(H + row * ldh + k);
+    f32x4 h = *hp;
+    h[0] = act_bwd<ACT>(h[0], g[0]);
+    h[1] = act_bwd<ACT>(h[1], g[1]);
+    h[2] = act_bwd<ACT>(h[2], g[2]);
+    h[3] = act_bwd<ACT>(h[3], g[3]);
+    *hp = h;
+  }
+}
+
+// Copy an LDS tile [R x W] (stride ld) to global rows (stride gld), float4 coalesced.
+template <int RT, int W>
+__device__ __forceinline__ void store_tile(float* __restrict__ dst, size_t gld,
+                                           const float* src, int ld) {
+  constexpr int R = 16 * RT;
+  constexpr int NV = R * W / 4;
+  for (int idx = threadIdx.x; idx < NV; idx += kThreads) {
+    const int row = idx / (W / 4), k = 4 * (idx % (W / 4));
+    *reinterpret_cast<f32x4*>(dst + (size_t)row * gld + k) =
+        *reinterpret_cast<const f32x4*>(src + row * ld + k);
+  }
+}
+
+template <int RT, int W>
+__device__ __forceinline__ void load_tile(float* dst, int ld,
+                                          const float* __restrict__ src, size_t gld) {
+  constexpr int R = 16 * RT;
+  constexpr int NV = R * W / 4;
+  for (int idx = threadIdx.x; idx < NV; idx += kThreads) {
+    const int row = idx / (W / 4), k = 4 * (idx % (W / 4));
+    *reinterpret_cast<f32x4*>(dst + row * ld + k) =
+        *reinterpret_cast<const f32x4*>(src + (size_t)row * gld + k);
+  }
+}
+
+// Stage the 256-wide code part of the network input for a row tile: LDS row i holds
+// code[min((row0+i)/rep, nrows_code-1)] (rows >= m are zero-filled).
+template <int RT>
+__device__ __forceinline__ void load_code_tile(float* dst, int ld,
+                                               const float* __restrict__ code, int64_t ld_code,
+                                               int rep, int64_t row0, int64_t m, bool vec4) {
+  constexpr int R = 16 * RT;
+  constexpr int NV = R * 64;
+  for (int idx = threadIdx.x; idx < NV; idx += kThreads) {
+    const int i = idx >> 6, k = 4 * (idx & 63);
+    const int64_t row = row0 + i;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < m) {
+      const float* p = code + (row / rep) * ld_code + k;
+      if (vec4) {
+        v = *reinterpret_cast<const f32x4*>(p);
+      } else {
+        v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3];
+      }
+    }
+    *reinterpret_cast<f32x4*>(dst + i * ld + k) = v;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// Sum over the 256 threads of a workgroup; result valid in thread 0.  `red` = 4 LDS floats.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) r = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return r;
+}
+
+}  // namespace ndp

@@ -1,0 +1,620 @@
+// ndp_kernels.hip -- gfx950 kernels of the GAN train step (see include/ndp.h).
+//
+//   k_g_fwd      Decoder.forward, one workgroup per 16*RT-row tile, all five layers fused
+//   k_d          Discriminator forward (+ BCE + backward data path), fused per row tile
+//   k_g_bwd      backward data path of the Decoder per row tile
+//   k_wgrad      all weight/bias gradients of one network: dW = dY^T X as MFMA blocks,
+//                rows split into chunks (split-K) -> partial slabs
+//   k_reduce_adam  sum the slabs (fixed order: bitwise reproducible), Adam, loss scalars
+//   k_ndiv       normalized-diversification loss + gradient (diversity.py)
+//   k_philox     uniform noise
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "ndp_device.h"
+
+namespace ndp {
+
+constexpr int CODE = 256;
+constexpr int ADIM = 4;
+constexpr int TAILLD = 16;   // LDS row stride of the narrow "tail" inputs (noise / action)
+
+struct GNet {
+  const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4, *w5, *b5;
+  int ld1, nz;
+};
+struct DNet {
+  const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;
+};
+
+// ================================================================ G forward
+struct GFwdArgs {
+  GNet net;
+  const float* code; int64_t ld_code; int code_rep; int code_vec4;
+  const float* noise; int64_t ld_noise;
+  int64_t m;
+  float *h1, *h2, *h3, *h4;   // [mpad x 128/64/128/256] or all null
+  float* action_hat;          // [m x 4]
+};
+
+template <int RT>
+constexpr int g_fwd_lds_floats() { return 16 * RT * (260 + TAILLD + 132 + 68 + 132 + 260 + 4); }
+
+template <int RT, int W1ALIGN>
+__global__ __launch_bounds__(kThreads) void k_g_fwd(GFwdArgs a) {
+  constexpr int R = 16 * RT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xc = smem;                 // R x 260
+  float* Xt = Xc + R * 260;         // R x 16   noise
+  float* H1 = Xt + R * TAILLD;      // R x 132
+  float* H2 = H1 + R * 132;         // R x 68
+  float* H3 = H2 + R * 68;          // R x 132
+  float* H4 = H3 + R * 132;         // R x 260
+  float* A = H4 + R * 260;          // R x 4
+  const int64_t row0 = (int64_t)blockIdx.x * R;
+  const GNet& n = a.net;
+
+  load_code_tile<RT>(Xc, 260, a.code, a.ld_code, a.code_rep, row0, a.m, a.code_vec4 != 0);
+  for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {
+    const int i = idx / TAILLD, t = idx % TAILLD;
+    const int64_t row = row0 + i;
+    Xt[idx] = (row < a.m && t < n.nz) ? a.noise[row * a.ld_noise + t] : 0.f;
+  }
+  __syncthreads();
+  layer_fwd<RT, 256, 128, ACT_RELU, W1ALIGN>(Xc, 260, n.w1, n.ld1, n.b1, H1, 132, Xt, TAILLD, n.nz, n.w1 + CODE);
+  __syncthreads();
+  layer_fwd<RT, 128, 64, ACT_RELU, 4>(H1, 132, n.w2, 128, n.b2, H2, 68, nullptr, 0, 0, nullptr);
+  __syncthreads();
+  layer_fwd<RT, 64, 128, ACT_RELU, 4>(H2, 68, n.w3, 64, n.b3, H3, 132, nullptr, 0, 0, nullptr);
+  __syncthreads();
+  layer_fwd<RT, 128, 256, ACT_RELU, 4>(H3, 132, n.w4, 128, n.b4, H4, 260, nullptr, 0, 0, nullptr);
+  __syncthreads();
+  layer_fwd_narrow<RT, 256, 4>(H4, 260, n.w5, n.b5, A, 4);
+  __syncthreads();
+  if (a.h1 != nullptr) {
+    store_tile<RT, 128>(a.h1 + row0 * 128, 128, H1, 132);
+    store_tile<RT, 64>(a.h2 + row0 * 64, 64, H2, 68);
+    store_tile<RT, 128>(a.h3 + row0 * 128, 128, H3, 132);
+    store_tile<RT, 256>(a.h4 + row0 * 256, 256, H4, 260);
+  }
+  if (threadIdx.x < R) {
+    const int64_t row = row0 + threadIdx.x;
+    if (row < a.m)
+      *reinterpret_cast<f32x4*>(a.action_hat + row * 4) = *reinterpret_cast<const f32x4*>(A + threadIdx.x * 4);
+  }
+}
+
+// ================================================================ D forward / backward
+struct DPass {
+  const float* action; int action_rep; float target;
+};
+struct DArgs {
+  DNet net;
+  DPass pass[2];
+  const float* code; int64_t ld_code; int code_rep; int code_vec4;
+  int64_t m, mpad;
+  const float* ext_dlogit;    // upstream dLoss/dlogit [m] (module backward) or null -> BCE
+  float inv_m;                // BCE mean scale (1 / global M)
+  int do_backward;
+  float* logits;              // [npass][mpad] or null
+  float *h1, *h2, *h3;        // [npass*mpad x 64/128/256] or null: saved for k_wgrad
+  float *dy1, *dy2, *dy3, *dl;
+  float* xa;                  // [npass*mpad x 4] action inputs, for k_wgrad
+  float* d_action;            // [m x 4] or null (pass 0)
+  float* loss_partials;       // [npass * ntiles] raw BCE sums, or null
+};
+
+template <int RT>
+constexpr int d_lds_floats() { return 16 * RT * (260 + TAILLD + 68 + 132 + 260 + 2) + 8; }
+
+template <int RT>
+__global__ __launch_bounds__(kThreads) void k_d(DArgs a) {
+  constexpr int R = 16 * RT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xc = smem;               // R x 260
+  float* Xt = Xc + R * 260;       // R x 16   action
+  float* H1 = Xt + R * TAILLD;    // R x 68
+  float* H2 = H1 + R * 68;        // R x 132
+  float* H3 = H2 + R * 132;       // R x 260
+  float* L = H3 + R * 260;        // R        logits
+  float* DL = L + R;              // R        dLoss/dlogit
+  float* red = DL + R;            // 4 (+4 pad)
+  const int ntiles = gridDim.x;
+  const int pass = blockIdx.y;
+  const int64_t row0 = (int64_t)blockIdx.x * R;
+  const int64_t grow0 = (int64_t)pass * a.mpad + row0;   // row in the [npass*mpad] buffers
+  const DNet& n = a.net;
+  const DPass ps = a.pass[pass];
+
+  load_code_tile<RT>(Xc, 260, a.code, a.ld_code, a.code_rep, row0, a.m, a.code_vec4 != 0);
+  for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {
+    const int i = idx / TAILLD, t = idx % TAILLD;
+    const int64_t row = row0 + i;
+    Xt[idx] = (row < a.m && t < ADIM) ? ps.action[(row / ps.action_rep) * ADIM + t] : 0.f;
+  }
+  __syncthreads();
+  // cat([action, code]) (models/gan.py:105): weight columns 0..3 = action, 4..259 = code
+  layer_fwd<RT, 256, 64, ACT_LRELU, 4>(Xc, 260, n.w1 + ADIM, 260, n.b1, H1, 68, Xt, TAILLD, ADIM, n.w1);
+  __syncthreads();
+  layer_fwd<RT, 64, 128, ACT_LRELU, 4>(H1, 68, n.w2, 64, n.b2, H2, 132, nullptr, 0, 0, nullptr);
+  __syncthreads();
+  layer_fwd<RT, 128, 256, ACT_LRELU, 4>(H2, 132, n.w3, 128, n.b3, H3, 260, nullptr, 0, 0, nullptr);
+  __syncthreads();
+  layer_fwd_narrow<RT, 256, 1>(H3, 260, n.w4, n.b4, L, 1);
+  __syncthreads();
+
+  float lsum = 0.f;
+  if (threadIdx.x < R) {
+    const int64_t row = row0 + threadIdx.x;
+    const float x = L[threadIdx.x];
+    float dl = 0.f;
+    if (row < a.m) {
+      // BCEWithLogits: max(x,0) - x*y + log1p(exp(-|x|));  d/dx = sigmoid(x) - y
+      lsum = fmaxf(x, 0.f) - x * ps.target + log1pf(expf(-fabsf(x)));
+      dl = a.ext_dlogit != nullptr ? a.ext_dlogit[row]
+                                   : (1.f / (1.f + expf(-x)) - ps.target) * a.inv_m;
+      if (a.logits != nullptr) a.logits[(int64_t)pass * a.mpad + row] = x;
+    }
+    DL[threadIdx.x] = dl;
+    if (a.dl != nullptr) a.dl[grow0 + threadIdx.x] = dl;
+  }
+  if (a.loss_partials != nullptr) {
+    const float tot = block_sum(lsum, red);
+    if (threadIdx.x == 0) a.loss_partials[pass * ntiles + blockIdx.x] = tot;
+  }
+  if (!a.do_backward) return;
+  if (a.h1 != nullptr) {
+    store_tile<RT, 64>(a.h1 + grow0 * 64, 64, H1, 68);
+    store_tile<RT, 128>(a.h2 + grow0 * 128, 128, H2, 132);
+    store_tile<RT, 256>(a.h3 + grow0 * 256, 256, H3, 260);
+    if (threadIdx.x < R)
+      *reinterpret_cast<f32x4*>(a.xa + (grow0 + threadIdx.x) * 4) =
+          *reinterpret_cast<const f32x4*>(Xt + threadIdx.x * TAILLD);
+  }
+  __syncthreads();
+  layer_dgrad_narrow<RT, 256, 1, ACT_LRELU>(DL, 1, n.w4, H3, 260);          // H3 := dY3
+  __syncthreads();
+  layer_dgrad<RT, 128, 256, ACT_LRELU>(H3, 260, n.w3, 128, H2, 132);         // H2 := dY2
+  __syncthreads();
+  layer_dgrad<RT, 64, 128, ACT_LRELU>(H2, 132, n.w2, 64, H1, 68);            // H1 := dY1
+  __syncthreads();
+  if (a.dy1 != nullptr) {
+    store_tile<RT, 64>(a.dy1 + grow0 * 64, 64, H1, 68);
+    store_tile<RT, 128>(a.dy2 + grow0 * 128, 128, H2, 132);
+    store_tile<RT, 256>(a.dy3 + grow0 * 256, 256, H3, 260);
+  }
+  if (a.d_action != nullptr && pass == 0 && threadIdx.x < R * ADIM) {
+    // dLoss/d action = dY1 . W1[:, 0:4]
+    const int i = threadIdx.x >> 2, j = threadIdx.x & 3;
+    const int64_t row = row0 + i;
+    float s = 0.f;
+#pragma unroll 8
+    for (int o = 0; o < 64; ++o) s = fmaf(H1[i * 68 + o], n.w1[o * 260 + j], s);
+    if (row < a.m) a.d_action[row * ADIM + j] = s;
+  }
+}
+
+// ================================================================ G backward (data path)
+struct GBwdArgs {
+  GNet net;
+  int64_t m;
+  const float *h1, *h2, *h3, *h4;   // saved by k_g_fwd [mpad x .]
+  const float* d_action;            // [m x 4]
+  const float* d_action2;           // [m x 4] added to d_action, or null (NDiv gradient)
+  float *dy1, *dy2, *dy3, *dy4, *dy5;   // [mpad x 128/64/128/256/4]
+};
+
+template <int RT>
+constexpr int g_bwd_lds_floats() { return 16 * RT * (132 + 68 + 132 + 260 + 4); }
+
+template <int RT>
+__global__ __launch_bounds__(kThreads) void k_g_bwd(GBwdArgs a) {
+  constexpr int R = 16 * RT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* H1 = smem;               // R x 132
+  float* H2 = H1 + R * 132;       // R x 68
+  float* H3 = H2 + R * 68;        // R x 132
+  float* H4 = H3 + R * 132;       // R x 260
+  float* DA = H4 + R * 260;       // R x 4
+  const int64_t row0 = (int64_t)blockIdx.x * R;
+  const GNet& n = a.net;
+
+  load_tile<RT, 128>(H1, 132, a.h1 + row0 * 128, 128);
+  load_tile<RT, 64>(H2, 68, a.h2 + row0 * 64, 64);
+  load_tile<RT, 128>(H3, 132, a.h3 + row0 * 128, 128);
+  load_tile<RT, 256>(H4, 260, a.h4 + row0 * 256, 256);
+  if (threadIdx.x < R) {
+    const int64_t row = row0 + threadIdx.x;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    if (row < a.m) {
+      g = *reinterpret_cast<const f32x4*>(a.d_action + row * 4);
+      if (a.d_action2 != nullptr) g += *reinterpret_cast<const f32x4*>(a.d_action2 + row * 4);
+    }
+    *reinterpret_cast<f32x4*>(DA + threadIdx.x * 4) = g;
+    *reinterpret_cast<f32x4*>(a.dy5 + row * 4) = g;
+  }
+  __syncthreads();
+  layer_dgrad_narrow<RT, 256, 4, ACT_RELU>(DA, 4, n.w5, H4, 260);     // H4 := dY4
+  __syncthreads();
+  layer_dgrad<RT, 128, 256, ACT_RELU>(H4, 260, n.w4, 128, H3, 132);   // H3 := dY3
+  __syncthreads();
+  layer_dgrad<RT, 64, 128, ACT_RELU>(H3, 132, n.w3, 64, H2, 68);      // H2 := dY2
+  __syncthreads();
+  layer_dgrad<RT, 128, 64, ACT_RELU>(H2, 68, n.w2, 128, H1, 132);     // H1 := dY1
+  __syncthreads();
+  store_tile<RT, 128>(a.dy1 + row0 * 128, 128, H1, 132);
+  store_tile<RT, 64>(a.dy2 + row0 * 64, 64, H2, 68);
+  store_tile<RT, 128>(a.dy3 + row0 * 128, 128, H3, 132);
+  store_tile<RT, 256>(a.dy4 + row0 * 256, 256, H4, 260);
+}
+
+// ================================================================ weight gradients
+// One job = one block of one layer's dW = sum_rows dY[row][j] * X[row][k]:
+//   FULL      64 j x 64 k, both operands read as float4 (j = 4c+u, k = 4c+v permuted tiles)
+//   SKINNY_B  64 j x (<=16) k   (the action / noise input columns)
+//   SKINNY_A  (<=16) j x 64 k   (the 4- and 1-wide output layers)
+// Workgroup (job, chunk): the 4 waves take interleaved 4-row steps of the chunk's rows,
+// accumulate in registers, then add their four results through LDS and store one slab.
+enum { WG_FULL = 0, WG_SKINNY_B = 1, WG_SKINNY_A = 2 };
+
+struct WgradJob {
+  const float* A;      // dY block: A[row*lda + j]
+  const float* B;      // X block:  B[brow*ldb + k], brow = min((row % b_rowmod) / b_rowdiv, b_rowmax)
+  int lda, ldb;
+  int a_cols, b_cols;
+  int b_rowmod, b_rowdiv, b_rowmax;
+  int b_vec;           // B rows 16-byte aligned
+  int dst_off, dst_ld; // slab[dst_off + j*dst_ld + k]
+  int bias_off;        // slab[bias_off + j] = sum_rows dY[row][j], or -1
+  int kind;
+};
+constexpr int kMaxJobs = 28;
+struct WgradArgs {
+  WgradJob job[kMaxJobs];
+  int njobs;
+  int rows;            // total rows (multiple of 16)
+  int rows_per_chunk;  // multiple of 16
+  float* slabs;        // [nchunks][slab_stride]
+  int64_t slab_stride;
+  int32_t* bump;       // Adam step counter to increment (block 0,0), or null
+};
+
+template <int MT, int NT, int KIND>
+__device__ __forceinline__ void wgrad_block(const WgradJob& jb, int rbeg, int rend,
+                                            float* slab, float* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  f32x4 acc[MT][NT];
+  float bs[MT];
+#pragma unroll
+  for (int u = 0; u < MT; ++u) {
+    bs[u] = 0.f;
+#pragma unroll
+    for (int v = 0; v < NT; ++v) acc[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll 2
+  for (int i0 = rbeg + 4 * wave; i0 < rend; i0 += 16) {
+    const int row = i0 + q;
+    float av[MT], bv[NT];
+    if (KIND == WG_SKINNY_A) {
+      av[0] = c < jb.a_cols ? jb.A[(size_t)row * jb.lda + c] : 0.f;
+    } else {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(jb.A + (size_t)row * jb.lda + 4 * c);
+#pragma unroll
+      for (int u = 0; u < MT; ++u) av[u] = t[u];
+    }
+    int brow = (row % jb.b_rowmod) / jb.b_rowdiv;
+    brow = brow < jb.b_rowmax ? brow : jb.b_rowmax;
+    if (KIND == WG_SKINNY_B) {
+      bv[0] = c < jb.b_cols ? jb.B[(size_t)brow * jb.ldb + c] : 0.f;
+    } else {
+      const float* p = jb.B + (size_t)brow * jb.ldb + 4 * c;
+      f32x4 t;
+      if (jb.b_vec) {
+        t = *reinterpret_cast<const f32x4*>(p);
+      } else {
+        t[0] = p[0]; t[1] = p[1]; t[2] = p[2]; t[3] = p[3];
+      }
+#pragma unroll
+      for (int v = 0; v < NT; ++v) bv[v] = t[v];
+    }
+#pragma unroll
+    for (int u = 0; u < MT; ++u) {
+      bs[u] += av[u];
+#pragma unroll
+      for (int v = 0; v < NT; ++v) acc[u][v] = mfma16(av[u], bv[v], acc[u][v]);
+    }
+  }
+  // ---- cross-wave reduction through LDS: tile image [JR][KC] per wave
+  constexpr int JR = KIND == WG_SKINNY_A ? 16 : 64;
+  constexpr int KC = KIND == WG_SKINNY_B ? 16 : 64;
+  float* mine = smem + wave * (JR * KC);
+  float* bsh = smem + kWaves * (JR * KC);   // [4][64] bias sums
+#pragma unroll
+  for (int u = 0; u < MT; ++u)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // C tile (u,v): lane holds M-row m' = 4q+i, N-col n' = c
+      const int j = KIND == WG_SKINNY_A ? (4 * q + i) : (4 * (4 * q + i) + u);
+      if (KIND == WG_SKINNY_B) {
+        mine[j * KC + c] = acc[u][0][i];
+      } else {
+        f32x4 t;
+#pragma unroll
+        for (int v = 0; v < NT; ++v) t[v] = acc[u][v][i];
+        *reinterpret_cast<f32x4*>(mine + j * KC + 4 * c) = t;
+      }
+    }
+#pragma unroll
+  for (int u = 0; u < MT; ++u) {
+    float s = bs[u];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (q == 0) bsh[wave * 64 + (KIND == WG_SKINNY_A ? c : 4 * c + u)] = s;
+  }
+  __syncthreads();
+  const int jn = jb.a_cols, kn = jb.b_cols;
+  for (int e = threadIdx.x; e < JR * KC / 4; e += kThreads) {
+    const int j = e / (KC / 4), k = 4 * (e % (KC / 4));
+    f32x4 s = *reinterpret_cast<const f32x4*>(smem + j * KC + k);
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) s += *reinterpret_cast<const f32x4*>(smem + w * (JR * KC) + j * KC + k);
+    if (j < jn) {
+      float* d = slab + jb.dst_off + (size_t)j * jb.dst_ld + k;
+      if (KIND != WG_SKINNY_B && ((jb.dst_ld | jb.dst_off) & 3) == 0) {
+        *reinterpret_cast<f32x4*>(d) = s;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (k + t < kn) d[t] = s[t];
+      }
+    }
+  }
+  if (jb.bias_off >= 0 && threadIdx.x < 64 && (int)threadIdx.x < jn) {
+    const int j = threadIdx.x;
+    slab[jb.bias_off + j] = bsh[j] + bsh[64 + j] + bsh[128 + j] + bsh[192 + j];
+  }
+}
+
+constexpr int wgrad_lds_floats() { return kWaves * 64 * 64 + kWaves * 64; }
+
+__global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WgradJob& jb = a.job[blockIdx.x];
+  const int rbeg = blockIdx.y * a.rows_per_chunk;
+  int rend = rbeg + a.rows_per_chunk;
+  rend = rend < a.rows ? rend : a.rows;
+  float* slab = a.slabs + (size_t)blockIdx.y * a.slab_stride;
+  if (a.bump != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.bump += 1;
+  const int kind = jb.kind;   // uniform per workgroup
+  if (kind == WG_FULL) wgrad_block<4, 4, WG_FULL>(jb, rbeg, rend, slab, smem);
+  else if (kind == WG_SKINNY_B) wgrad_block<4, 1, WG_SKINNY_B>(jb, rbeg, rend, slab, smem);
+  else wgrad_block<1, 4, WG_SKINNY_A>(jb, rbeg, rend, slab, smem);
+}
+
+// ================================================================ slab reduce + Adam + losses
+struct LossTerm {
+  const float* partials; int count; float scale; int slot;   // losses[slot] = scale * sum
+};
+struct ReduceArgs {
+  const float* slabs; int nchunks; int64_t slab_stride; int64_t n;
+  float* grad;                         // [n] or null
+  float *params, *exp_avg, *exp_avg_sq;   // Adam (params null -> no update)
+  const int32_t* step;                 // device step count, already incremented
+  float lr, beta1, beta2, eps;
+  LossTerm loss[3]; int nloss;
+  float* losses; float* loss_sums;
+};
+
+__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v,
+                                            float step_size, float bc2_sqrt, float b1, float b2, float eps) {
+  m = m + (g - m) * (1.f - b1);                 // exp_avg.lerp_(grad, 1 - beta1)
+  v = v * b2 + (1.f - b2) * g * g;              // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+  const float denom = sqrtf(v) / bc2_sqrt + eps;
+  p = p - step_size * (m / denom);              // param.addcdiv_(exp_avg, denom, -step_size)
+}
+
+__device__ __forceinline__ void adam_scalars(const int32_t* step, float lr, float b1, float b2,
+                                             float* sh, float& step_size, float& bc2_sqrt) {
+  if (threadIdx.x == 0) {
+    const double t = (double)*step;
+    const double bc1 = 1.0 - pow((double)b1, t);
+    const double bc2 = 1.0 - pow((double)b2, t);
+    sh[0] = (float)((double)lr / bc1);
+    sh[1] = (float)sqrt(bc2);
+  }
+  __syncthreads();
+  step_size = sh[0];
+  bc2_sqrt = sh[1];
+}
+
+__global__ __launch_bounds__(kThreads) void k_reduce_adam(ReduceArgs a) {
+  __shared__ float sh[8];
+  float step_size = 0.f, bc2_sqrt = 1.f;
+  if (a.params != nullptr) adam_scalars(a.step, a.lr, a.beta1, a.beta2, sh, step_size, bc2_sqrt);
+  const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (p < a.n) {
+    float g = 0.f;
+    for (int ch = 0; ch < a.nchunks; ++ch) g += a.slabs[(size_t)ch * a.slab_stride + p];
+    if (a.grad != nullptr) a.grad[p] = g;
+    if (a.params != nullptr) {
+      float pv = a.params[p], m = a.exp_avg[p], v = a.exp_avg_sq[p];
+      adam_update(pv, g, m, v, step_size, bc2_sqrt, a.beta1, a.beta2, a.eps);
+      a.params[p] = pv;
+      a.exp_avg[p] = m;
+      a.exp_avg_sq[p] = v;
+    }
+  }
+  if (blockIdx.x == 0) {
+    for (int t = 0; t < a.nloss; ++t) {
+      const LossTerm lt = a.loss[t];
+      float s = 0.f;
+      for (int i = threadIdx.x; i < lt.count; i += kThreads) s += lt.partials[i];
+      s = block_sum(s, sh + 4);
+      if (threadIdx.x == 0) {
+        s *= lt.scale;
+        a.losses[lt.slot] = s;
+        if (a.loss_sums != nullptr) a.loss_sums[lt.slot] += s;
+      }
+    }
+  }
+}
+
+__global__ void k_bump(int32_t* ctr) { *ctr += 1; }
+
+struct AdamArgs {
+  float *params, *exp_avg, *exp_avg_sq; const float* grad; int64_t n;
+  const int32_t* step; float lr, beta1, beta2, eps;
+};
+__global__ __launch_bounds__(kThreads) void k_adam(AdamArgs a) {
+  __shared__ float sh[4];
+  float step_size, bc2_sqrt;
+  adam_scalars(a.step, a.lr, a.beta1, a.beta2, sh, step_size, bc2_sqrt);
+  const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (p < a.n) {
+    float pv = a.params[p], m = a.exp_avg[p], v = a.exp_avg_sq[p];
+    adam_update(pv, a.grad[p], m, v, step_size, bc2_sqrt, a.beta1, a.beta2, a.eps);
+    a.params[p] = pv;
+    a.exp_avg[p] = m;
+    a.exp_avg_sq[p] = v;
+  }
+}
+
+// ================================================================ NDiv (diversity.py)
+// One thread per (row n, sample i); a workgroup holds G = 256/K rows in LDS.
+// Pass 1: row sums s_i = sum_j d_ij for x and z.  Pass 2: hinge terms and the gradient
+//   dL/dx_i = sum_j -(m_ij/s_i + m_ji/s_j) (x_i - x_j)/d_ij   (0 where d_ij == 0).
+struct NdivArgs {
+  const float* x; int cx; const float* z; int cz;
+  int64_t n; int k; int rows_per_block;
+  float grad_scale;
+  float* grad;         // [n*k x cx] or null
+  float* partials;     // [gridDim.x]
+};
+constexpr int kNdivMaxC = 16;
+
+__global__ __launch_bounds__(kThreads) void k_ndiv(NdivArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int k = a.k, cx = a.cx, cz = a.cz, G = a.rows_per_block;
+  float* xs = smem;                     // G*k*cx
+  float* zs = xs + G * k * cx;          // G*k*cz
+  float* sx = zs + G * k * cz;          // G*k
+  float* sz = sx + G * k;               // G*k
+  float* red = sz + G * k;              // 4
+  const int64_t n0 = (int64_t)blockIdx.x * G;
+  const int64_t nrows = (a.n - n0) < G ? (a.n - n0) : G;
+  const int nact = (int)nrows * k;
+  for (int idx = threadIdx.x; idx < nact * cx; idx += kThreads) xs[idx] = a.x[n0 * k * cx + idx];
+  for (int idx = threadIdx.x; idx < nact * cz; idx += kThreads) zs[idx] = a.z[n0 * k * cz + idx];
+  __syncthreads();
+  const int t = threadIdx.x;
+  const bool on = t < nact;
+  const int g = on ? t / k : 0, i = on ? t % k : 0;
+  float xi[kNdivMaxC], zi[kNdivMaxC];
+#pragma unroll
+  for (int d = 0; d < kNdivMaxC; ++d) {
+    xi[d] = (on && d < cx) ? xs[(g * k + i) * cx + d] : 0.f;
+    zi[d] = (on && d < cz) ? zs[(g * k + i) * cz + d] : 0.f;
+  }
+  if (on) {
+    float ssx = 0.f, ssz = 0.f;
+    for (int j = 0; j < k; ++j) {
+      float dx2 = 0.f, dz2 = 0.f;
+#pragma unroll
+      for (int d = 0; d < kNdivMaxC; ++d) {
+        if (d < cx) { const float e = xi[d] - xs[(g * k + j) * cx + d]; dx2 = fmaf(e, e, dx2); }
+        if (d < cz) { const float e = zi[d] - zs[(g * k + j) * cz + d]; dz2 = fmaf(e, e, dz2); }
+      }
+      ssx += sqrtf(dx2);
+      ssz += sqrtf(dz2);
+    }
+    sx[g * k + i] = ssx;
+    sz[g * k + i] = ssz;
+  }
+  __syncthreads();
+  float loss = 0.f;
+  if (on) {
+    const float sxi = sx[g * k + i], szi = sz[g * k + i];
+    float gr[kNdivMaxC];
+#pragma unroll
+    for (int d = 0; d < kNdivMaxC; ++d) gr[d] = 0.f;
+    for (int j = 0; j < k; ++j) {
+      float dx2 = 0.f, dz2 = 0.f;
+      float e[kNdivMaxC];
+#pragma unroll
+      for (int d = 0; d < kNdivMaxC; ++d) {
+        e[d] = 0.f;
+        if (d < cx) { e[d] = xi[d] - xs[(g * k + j) * cx + d]; dx2 = fmaf(e[d], e[d], dx2); }
+        if (d < cz) { const float f = zi[d] - zs[(g * k + j) * cz + d]; dz2 = fmaf(f, f, dz2); }
+      }
+      const float dx = sqrtf(dx2), dz = sqrtf(dz2);
+      const float sxj = sx[g * k + j], szj = sz[g * k + j];
+      // z_delta * 0.8 - x_delta (diversity.py:40); relu propagates NaN like torch
+      const float hij = __fsub_rn(__fmul_rn(dz / szi, 0.8f), dx / sxi);
+      const float hji = __fsub_rn(__fmul_rn(dz / szj, 0.8f), dx / sxj);
+      loss += (hij > 0.f || hij != hij) ? hij : 0.f;
+      float w = (hij > 0.f ? 1.f / sxi : 0.f) + (hji > 0.f ? 1.f / sxj : 0.f);
+      if (hij != hij || hji != hji) w = hij + hji;          // NaN propagates into the gradient
+      if (dx > 0.f) {
+        const float f = w / dx;
+#pragma unroll
+        for (int d = 0; d < kNdivMaxC; ++d)
+          if (d < cx) gr[d] = fmaf(-f, e[d], gr[d]);
+      } else if (w != w) {
+#pragma unroll
+        for (int d = 0; d < kNdivMaxC; ++d)
+          if (d < cx) gr[d] = w;
+      }
+    }
+    if (a.grad != nullptr) {
+#pragma unroll
+      for (int d = 0; d < kNdivMaxC; ++d)
+        if (d < cx) a.grad[(n0 * k + t) * cx + d] = a.grad_scale * gr[d];
+    }
+  }
+  const float tot = block_sum(loss, red);
+  if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kThreads) void k_sum_partials(const float* partials, int count,
+                                                           float scale, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < count; i += kThreads) s += partials[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) *out = s * scale;
+}
+
+// ================================================================ uniform noise (Philox-4x32-10)
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__global__ __launch_bounds__(kThreads) void k_philox(float* out, int64_t n, uint64_t seed,
+                                                     const int32_t* offset_dev) {
+  const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;   // one thread = 4 floats
+  if (idx * 4 >= n) return;
+  const uint32_t off = offset_dev != nullptr ? (uint32_t)*offset_dev : 0u;
+  uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), off, 0x6e647021u};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (idx * 4 + j < n) out[idx * 4 + j] = (float)(c[j] >> 8) * (1.0f / 16777216.0f);   // [0,1)
+}
+
+}  // namespace ndp
+
+#include "ndp_capi.inc"

@@ -1,0 +1,206 @@
+"""Fused GAN train step -- the hot loop of the reference's `train_gan.train`
+(train_gan.py:159-203) as a handful of gfx950 kernels per step, optionally
+captured in a HIP graph, optionally data-parallel.
+
+One step = `discrim_steps` x phase A (`ndp_step_d_grads`: [G forward,] D(real),
+D(fake), BCE, D backward, D Adam) + phase B (`ndp_step_g_grads`: D(fake) with the
+updated D, G loss, NDiv, backward through D and G, G Adam).  See include/ndp.h.
+
+Data parallelism: each rank holds `flat` of the
+`flat_global` rows.  BCE is a mean over the global row count (inv_m_global),
+NDiv is a sum, so per-rank gradients are SUMMED by `reduce_fn` (an all-reduce over
+RCCL), after which every rank applies the same Adam update to its replica.
+"""
+import ctypes
+
+import torch
+
+from . import _capi
+from .models.gan import ACTION_DIM, CODE_DIM, Decoder, Discriminator
+
+
+class GanTrainer:
+    def __init__(self, decoder: Decoder, discriminator: Discriminator, *, flat: int, num_sample: int,
+                 lr: float = 2e-4, betas=(0.5, 0.999), eps: float = 1e-8, pairwise_div_factor: float = 0.1,
+                 discrim_steps: int = 1, flat_global: int = None, reduce_fn=None, use_graph: bool = True,
+                 noise_seed: int = 0):
+        self.lib = _capi.load()
+        self.decoder, self.discriminator = decoder, discriminator
+        self.noise_dim = decoder.noise_dim
+        self.flat, self.k = int(flat), int(num_sample)
+        self.flat_global = int(flat_global) if flat_global is not None else self.flat
+        self.m = self.flat * self.k
+        self.discrim_steps = int(discrim_steps)
+        self.reduce_fn = reduce_fn
+        self.use_graph = bool(use_graph)
+        self.noise_seed = int(noise_seed)
+        self.g_flat = decoder.flat_parameters()
+        self.d_flat = discriminator.flat_parameters()
+        dev = self.g_flat.device
+        if dev.type != "cuda":
+            raise _capi.NdpError("GanTrainer needs the networks on a ROCm GPU (got %s); there is no CPU path" % dev)
+        self.device = dev
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.g_grad, self.d_grad = torch.zeros_like(self.g_flat), torch.zeros_like(self.d_flat)
+        self.g_m, self.g_v = torch.zeros_like(self.g_flat), torch.zeros_like(self.g_flat)
+        self.d_m, self.d_v = torch.zeros_like(self.d_flat), torch.zeros_like(self.d_flat)
+        self.g_step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.d_step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.noise_ctr = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.losses_dev = torch.zeros(4, **f32)
+        self.loss_sums = torch.zeros(4, **f32)
+        mpad = _capi.pad_rows(self.m)
+        self.action_hat = torch.zeros(mpad, ACTION_DIM, **f32)
+        # static input buffers (graph replay needs fixed addresses)
+        self.codes = torch.zeros(self.flat, CODE_DIM, **f32)
+        self.actions = torch.zeros(self.flat, ACTION_DIM, **f32)
+        self.noise = torch.zeros(self.flat, self.k, self.noise_dim, **f32)
+        self.cfg = _capi.StepConfig(
+            noise_dim=self.noise_dim, num_sample=self.k, flat=self.flat,
+            inv_m_global=1.0 / float(self.flat_global * self.k), pairwise_div_factor=float(pairwise_div_factor),
+            lr=float(lr), beta1=float(betas[0]), beta2=float(betas[1]), eps=float(eps),
+            fuse_adam=0 if reduce_fn is not None else 1, reserved=0)
+        nws = self.lib.ndp_step_workspace_floats(ctypes.byref(self.cfg))
+        if nws <= 0:
+            raise _capi.NdpError("bad step configuration (flat=%d, num_sample=%d)" % (self.flat, self.k))
+        self.workspace = torch.empty(nws, **f32)
+        self._graphs = None
+        self._bind()
+
+    # -- plumbing ---------------------------------------------------------------
+    def _bind(self):
+        self.g_flat = self.decoder.flat_parameters()
+        self.d_flat = self.discriminator.flat_parameters()
+        p = _capi.ptr
+        self.buf = _capi.StepBuffers(
+            g_params=p(self.g_flat), g_grad=p(self.g_grad), g_exp_avg=p(self.g_m), g_exp_avg_sq=p(self.g_v),
+            d_params=p(self.d_flat), d_grad=p(self.d_grad), d_exp_avg=p(self.d_m), d_exp_avg_sq=p(self.d_v),
+            g_step=p(self.g_step), d_step=p(self.d_step), losses=p(self.losses_dev), loss_sums=p(self.loss_sums),
+            action_hat=p(self.action_hat), workspace=p(self.workspace))
+
+    def _phase_a(self, first):
+        _capi.check(self.lib.ndp_step_d_grads(ctypes.byref(self.cfg), ctypes.byref(self.buf), _capi.ptr(self.codes),
+                                              _capi.ptr(self.actions), _capi.ptr(self.noise), 1 if first else 0,
+                                              _capi.stream_ptr()), "ndp_step_d_grads")
+
+    def _phase_b(self):
+        _capi.check(self.lib.ndp_step_g_grads(ctypes.byref(self.cfg), ctypes.byref(self.buf), _capi.ptr(self.codes),
+                                              _capi.ptr(self.actions), _capi.ptr(self.noise), _capi.stream_ptr()),
+                    "ndp_step_g_grads")
+
+    def _adam(self, flat, grad, m, v, step):
+        c = self.cfg
+        _capi.check(self.lib.ndp_adam_step(_capi.ptr(flat), _capi.ptr(grad), _capi.ptr(m), _capi.ptr(v), flat.numel(),
+                                           _capi.ptr(step), c.lr, c.beta1, c.beta2, c.eps, _capi.stream_ptr()),
+                    "ndp_adam_step")
+
+    def _device_noise(self):
+        _capi.check(self.lib.ndp_uniform_noise(_capi.ptr(self.noise), self.noise.numel(), self.noise_seed,
+                                               _capi.ptr(self.noise_ctr), _capi.stream_ptr()), "ndp_uniform_noise")
+        self.noise_ctr.add_(1)
+
+    # the step as a list of segments; between segments the data-parallel driver
+    # all-reduces the gradient the previous segment produced
+    def _segments(self, device_noise):
+        segs = []
+
+        def seg_d(first):
+            def run():
+                if first and device_noise:
+                    self._device_noise()
+                self._phase_a(first)
+            return run
+
+        def d_update():
+            self._adam(self.d_flat, self.d_grad, self.d_m, self.d_v, self.d_step)
+
+        def g_update():
+            self._adam(self.g_flat, self.g_grad, self.g_m, self.g_v, self.g_step)
+
+        fused = self.reduce_fn is None
+        for it in range(self.discrim_steps):
+            segs.append((seg_d(it == 0), None if fused else self.d_grad))
+            if not fused:
+                segs.append((d_update, None))
+        segs.append((self._phase_b, None if fused else self.g_grad))
+        if not fused:
+            segs.append((g_update, None))
+        return segs
+
+    def _run_eager(self, device_noise):
+        for fn, grad in self._segments(device_noise):
+            fn()
+            if grad is not None:
+                self.reduce_fn(grad)
+
+    def _build_graphs(self, device_noise):
+        """Capture maximal runs of segments that need no collective in between."""
+        # load the code object / set kernel attributes outside of capture
+        tmp = torch.empty(4, dtype=torch.float32, device=self.device)
+        _capi.check(self.lib.ndp_uniform_noise(_capi.ptr(tmp), 4, 0, None, _capi.stream_ptr()), "warm-up")
+        torch.cuda.synchronize(self.device)
+        plan, run = [], []
+        for fn, grad in self._segments(device_noise):
+            run.append(fn)
+            if grad is not None:
+                plan.append((run, grad))
+                run = []
+        if run:
+            plan.append((run, None))
+        graphs = []
+        for fns, grad in plan:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for fn in fns:
+                    fn()
+            graphs.append((g, grad))
+        return graphs
+
+    # -- public -----------------------------------------------------------------
+    def step(self, codes=None, actions=None, noise=None):
+        """One training iteration.  `codes` [flat,256], `actions` [flat,4]: this rank's
+        shard (None = keep the buffers' current contents); `noise` [flat,K,nz] or None to
+        draw U[0,1) on the device."""
+        if self.g_flat.data_ptr() != self.decoder.flat_parameters().data_ptr() or \
+                self.d_flat.data_ptr() != self.discriminator.flat_parameters().data_ptr():
+            self._bind()
+            self._graphs = None
+        if codes is not None:
+            self.codes.copy_(codes.reshape(self.flat, CODE_DIM), non_blocking=True)
+        if actions is not None:
+            self.actions.copy_(actions.reshape(self.flat, ACTION_DIM), non_blocking=True)
+        device_noise = noise is None
+        if not device_noise:
+            self.noise.copy_(noise.reshape(self.flat, self.k, self.noise_dim), non_blocking=True)
+        if not self.use_graph:
+            self._run_eager(device_noise)
+            return
+        key = bool(device_noise)
+        if self._graphs is None:
+            self._graphs = {}
+        if key not in self._graphs:
+            # capture performs no work; the first replay below is the step itself
+            self._graphs[key] = self._build_graphs(device_noise)
+        for g, grad in self._graphs[key]:
+            g.replay()
+            if grad is not None:
+                self.reduce_fn(grad)
+
+    def losses(self):
+        """(D_loss, G_loss, pair_div) of the last step as Python floats (synchronises)."""
+        v = self.losses_dev.tolist()
+        return v[0], v[1], v[2]
+
+    def pop_loss_sums(self):
+        """Running sums of the three losses since the last call (one sync per epoch
+        instead of the reference's three per step, train_gan.py:205-207)."""
+        v = self.loss_sums.tolist()
+        self.loss_sums.zero_()
+        return v[0], v[1], v[2]
+
+    def load_adam_state(self, g_state, d_state):
+        """Teacher-forcing hook for parity tests: {'m': flat, 'v': flat, 't': int} per network."""
+        for (m, v, step), st in (((self.g_m, self.g_v, self.g_step), g_state), ((self.d_m, self.d_v, self.d_step), d_state)):
+            m.copy_(st["m"])
+            v.copy_(st["v"])
+            step.fill_(int(st["t"]))

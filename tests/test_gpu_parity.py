@@ -1,0 +1,393 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the
+golden vectors of the reference.  Run on the MI355X box with `-m gpu`.
+
+Tolerances (BASELINE.md section 2 / SURVEY.md section 8c):
+  action_hat, logits, D/G loss: |d| <= 1e-4 absolute
+  NDiv sum: |d| <= 1e-4 * max(1, |ref|)
+  gradients: |d| <= 1e-5 * max(1, net-wide max |g|)   (fp32 cancellation noise)
+  parameters after Adam: see _params_close (teacher-forced, per step)
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_params, load_golden
+from oracle import gan_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _close(a, b, atol, what):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, "%s: shape %s vs %s" % (what, a.shape, b.shape)
+    assert np.isfinite(a).all(), "%s: non-finite values" % what
+    err = np.abs(a - b).max() if a.size else 0.0
+    assert err <= atol, "%s: max |diff| %.3e > %.1e" % (what, err, atol)
+
+
+def _ndiv_close(a, ref, what):
+    a, ref = float(a), float(ref)
+    assert abs(a - ref) <= 1e-4 * max(1.0, abs(ref)), "%s: %.6f vs %.6f" % (what, a, ref)
+
+
+def _params_close(p, p_ref, g_ref, g_scale, lr, what):
+    """Post-Adam parameters from identical pre-step state: within the Adam bound
+    everywhere, and beyond 1e-4 only where the gradient is under its fp32 noise floor
+    (see tests/test_oracle_golden.py::_params_close)."""
+    p = p.detach().cpu().double().numpy()
+    p_ref = p_ref.detach().cpu().double().numpy()
+    err = np.abs(p - p_ref)
+    assert err.max() <= 2.5 * lr, "%s: max |diff| %.3e beyond the Adam bound" % (what, err.max())
+    bad = err > 1e-4
+    if bad.any():
+        floor = 2e-6 * max(1.0, g_scale)
+        g = np.abs(g_ref.detach().cpu().numpy())[bad].max()
+        assert g <= floor, "%s: mismatch at a well-conditioned gradient (|g| %.2e > %.2e)" % (what, g, floor)
+
+
+def _flat(params):
+    return torch.cat([p.reshape(-1) for p in params.values()])
+
+
+def _load_modules(g, d, nz):
+    from ndivplanning_amd.models.gan import Decoder, Discriminator
+    dec, dis = Decoder(nz), Discriminator()
+    dec.load_state_dict(g)
+    dis.load_state_dict(d)
+    return dec.to(DEV), dis.to(DEV)
+
+
+# ------------------------------------------------------------------ NDiv
+@pytest.mark.parametrize("name", ["k6", "k32", "k2", "k3c5", "coin"])
+def test_ndiv_golden(name):
+    from ndivplanning_amd import diversity
+    rec = load_golden("ndiv_cases")
+    x = torch.from_numpy(rec[name + ".x"]).to(DEV).requires_grad_(True)
+    z = torch.from_numpy(rec[name + ".z"]).to(DEV)
+    loss = diversity.compute_pairwise_divergence(x, z)
+    loss.backward()
+    _ndiv_close(loss.item(), rec[name + ".loss"], name)
+    _close(x.grad, rec[name + ".grad"], 1e-5, name + " grad")
+    if name + ".pair_x" in rec:
+        _close(diversity.compute_pair_distance(x.detach()), rec[name + ".pair_x"], 1e-6, "pair_distance")
+        _close(diversity.compute_pairwise(x.detach()), rec[name + ".pairwise_x"], 1e-6, "pairwise")
+        _close(diversity.compute_pair_unnormal_distance(x.detach()), rec[name + ".unnormal_x"], 1e-6, "unnormal")
+
+
+def test_ndiv_k1_nan_and_squeeze():
+    from ndivplanning_amd import diversity
+    rec = load_golden("ndiv_cases")
+    x = torch.from_numpy(rec["k1.x"]).to(DEV).requires_grad_(True)
+    z = torch.from_numpy(rec["k1.z"]).to(DEV)
+    loss = diversity.compute_pairwise_divergence(x, z)
+    loss.backward()
+    assert torch.isnan(loss) and np.isnan(rec["k1.loss"])
+    assert np.array_equal(np.isnan(x.grad.cpu().numpy()), np.isnan(rec["k1.grad"]))
+    # trailing singleton dims, as train_gan.py:195 passes them
+    xs = torch.from_numpy(rec["sq.x"]).to(DEV)
+    zs = torch.from_numpy(rec["sq.z"]).to(DEV)
+    _ndiv_close(diversity.compute_pairwise_divergence(xs, zs.squeeze(3).squeeze(3)).item(), rec["sq.loss"], "sq")
+
+
+@pytest.mark.parametrize("n,k", [(7168 // 8, 32), (448, 6), (5, 256), (1000, 1 + 6)])
+def test_ndiv_vs_oracle_large(n, k):
+    from ndivplanning_amd import diversity
+    gen = torch.Generator().manual_seed(n + k)
+    x = torch.randn(n, k, 4, generator=gen) * 0.05
+    z = torch.rand(n, k, 2, generator=gen)
+    ref_loss, ref_grad = O.ndiv_loss_and_grad(x.double(), z.double())
+    xg = x.to(DEV).requires_grad_(True)
+    loss = diversity.compute_pairwise_divergence(xg, z.to(DEV))
+    loss.backward()
+    _ndiv_close(loss.item(), ref_loss.item(), "loss")
+    _close(xg.grad, ref_grad, 1e-4 * max(1.0, ref_grad.abs().max().item()), "grad")
+
+
+# ------------------------------------------------------------------ module forward / backward
+@pytest.mark.parametrize("m,nz", [(42, 2), (672, 2), (2688, 2), (100, 1), (33, 5), (64, 16), (20000, 2)])
+def test_decoder_forward_backward(m, nz):
+    g, d = O.init_params(1, nz)
+    dec, _ = _load_modules(g, d, nz)
+    gen = torch.Generator().manual_seed(m)
+    z = torch.cat([torch.randn(m, 256, generator=gen), torch.rand(m, nz, generator=gen)], dim=1)
+    up = torch.randn(m, 4, generator=gen)
+    gr = {k: v.clone().requires_grad_(True) for k, v in g.items()}
+    ref = O.g_forward(gr, z)
+    (ref * up).sum().backward()
+    out = dec(z.to(DEV))
+    _close(out, ref, 1e-4, "action_hat")
+    (out * up.to(DEV)).sum().backward()
+    scale = max(1.0, max(v.grad.abs().max().item() for v in gr.values()))
+    for name, p in dec.named_parameters():
+        _close(p.grad, gr[name].grad, 1e-5 * scale, "dG/d" + name)
+
+
+@pytest.mark.parametrize("m", [42, 672, 2688, 17, 20000])
+def test_discriminator_forward_backward(m):
+    g, d = O.init_params(2, 2)
+    _, dis = _load_modules(g, d, 2)
+    gen = torch.Generator().manual_seed(m)
+    action = torch.rand(m, 4, generator=gen) * 2 - 1
+    code = torch.randn(m, 256, generator=gen)
+    up = torch.randn(m, 1, generator=gen) / m
+    dr = {k: v.clone().requires_grad_(True) for k, v in d.items()}
+    a_ref = action.clone().requires_grad_(True)
+    ref = O.d_forward(dr, a_ref, code)
+    (ref * up).sum().backward()
+    a_dev = action.to(DEV).requires_grad_(True)
+    out = dis(a_dev, code.to(DEV))
+    _close(out, ref, 1e-4, "logits")
+    (out * up.to(DEV)).sum().backward()
+    scale = max(1.0, max(v.grad.abs().max().item() for v in dr.values()))
+    for name, p in dis.named_parameters():
+        _close(p.grad, dr[name].grad, 1e-5 * scale, "dD/d" + name)
+    _close(a_dev.grad, a_ref.grad, 1e-6, "d action")
+
+
+def test_modules_fail_loudly_on_cpu():
+    from ndivplanning_amd import _capi, diversity
+    from ndivplanning_amd.models.gan import Decoder, Discriminator
+    with pytest.raises(_capi.NdpError):
+        Decoder(2)(torch.zeros(4, 258))
+    with pytest.raises(_capi.NdpError):
+        Discriminator()(torch.zeros(4, 4), torch.zeros(4, 256))
+    with pytest.raises(_capi.NdpError):
+        diversity.compute_pairwise_divergence(torch.zeros(2, 3, 4), torch.zeros(2, 3, 2))
+
+
+def test_reference_style_loop_with_modules_matches_golden_step0():
+    """train_gan.py:159-203 written against the mirrored modules + torch.optim.Adam on the
+    GPU, checked against the reference's own step-0 numbers (incl. every gradient)."""
+    from ndivplanning_amd import diversity
+    rec = load_golden("step_tiny_full")
+    g, d = golden_params(rec, "g0."), golden_params(rec, "d0.")
+    dec, dis = _load_modules(g, d, 2)
+    codes = torch.from_numpy(rec["codes"]).to(DEV)
+    actions = torch.from_numpy(rec["actions"]).to(DEV)
+    noise = torch.from_numpy(rec["noise"][0]).to(DEV)
+    flat, k = noise.shape[0], noise.shape[1]
+    m = flat * k
+    g_opt = torch.optim.Adam(dec.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    d_opt = torch.optim.Adam(dis.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    bce = torch.nn.BCEWithLogitsLoss()
+    action_rep = torch.repeat_interleave(actions, k, dim=0)
+    codes_rep = torch.repeat_interleave(codes, k, dim=0)
+    z = torch.cat([codes[:, None, :].expand(-1, k, -1), noise], dim=2).reshape(m, -1)
+    action_hat = dec(z)
+    _close(action_hat, rec["s0.action_hat"], 1e-4, "action_hat")
+    ones, zeros = torch.ones(m, device=DEV), torch.zeros(m, device=DEV)
+    l_real, l_fake = dis(action_rep, codes_rep), dis(action_hat, codes_rep)
+    d_loss = bce(l_real.squeeze(1), ones) + bce(l_fake.squeeze(1), zeros)
+    d_opt.zero_grad()
+    d_loss.backward(retain_graph=True)
+    _close(l_real, rec["s0.logits_real"], 1e-4, "logits_real")
+    _close(l_fake, rec["s0.logits_fake"], 1e-4, "logits_fake")
+    dscale = max(1.0, max(np.abs(rec["s0.dgrad." + n]).max() for n, _ in dis.named_parameters()))
+    for n, p in dis.named_parameters():
+        _close(p.grad, rec["s0.dgrad." + n], 1e-5 * dscale, "dgrad " + n)
+    d_opt.step()
+    l_gen = dis(action_hat, codes_rep)
+    g_loss = bce(l_gen.squeeze(1), ones)
+    pair_div = diversity.compute_pairwise_divergence(action_hat.view(flat, k, -1), noise[..., None, None].squeeze(3).squeeze(3))
+    total = g_loss + 0.1 * pair_div
+    g_opt.zero_grad()
+    total.backward()
+    gscale = max(1.0, max(np.abs(rec["s0.ggrad." + n]).max() for n, _ in dec.named_parameters()))
+    for n, p in dec.named_parameters():
+        _close(p.grad, rec["s0.ggrad." + n], 1e-5 * gscale, "ggrad " + n)
+    g_opt.step()
+    ref = rec["s0.losses"]
+    _close(d_loss, ref[0], 1e-4, "D_loss")
+    _close(g_loss, ref[1], 1e-4, "G_loss")
+    _ndiv_close(pair_div.item(), ref[2], "pair_div")
+
+
+# ------------------------------------------------------------------ fused trainer
+def _teacher_forced_run(case, use_graph):
+    from ndivplanning_amd.trainer import GanTrainer
+    rec = load_golden(case)
+    seed, batch, k, nz, steps, dsteps, traj = [int(v) for v in rec["meta"]]
+    factor, lr = float(rec["factor"]), float(rec["lr"])
+    g, d = golden_params(rec, "g0."), golden_params(rec, "d0.")
+    codes, actions = torch.from_numpy(rec["codes"]), torch.from_numpy(rec["actions"])
+    noise = torch.from_numpy(rec["noise"])
+    flat = codes.shape[0]
+    teacher = O.AutogradTrainer(g, d, lr=lr, pairwise_div_factor=factor)
+    dec, dis = _load_modules(g, d, nz)
+    tr = GanTrainer(dec, dis, flat=flat, num_sample=k, lr=lr, pairwise_div_factor=factor,
+                    discrim_steps=dsteps, use_graph=use_graph)
+    for s in range(steps):
+        st = teacher.export_state()
+        with torch.no_grad():
+            tr.g_flat.copy_(_flat(st["g"]))
+            tr.d_flat.copy_(_flat(st["d"]))
+        tr.load_adam_state({"m": _flat(st["g_opt"]["m"]), "v": _flat(st["g_opt"]["v"]), "t": st["g_opt"]["t"]},
+                           {"m": _flat(st["d_opt"]["m"]), "v": _flat(st["d_opt"]["v"]), "t": st["d_opt"]["t"]})
+        ref = teacher.step(codes, actions, noise[s], discrim_steps=dsteps)
+        tr.step(codes.to(DEV), actions.to(DEV), noise[s].to(DEV))
+        d_loss, g_loss, pd = tr.losses()
+        gold = rec["s%d.losses" % s]
+        _close(d_loss, gold[0], 1e-4, "%s D_loss step %d" % (case, s))
+        _close(g_loss, gold[1], 1e-4, "%s G_loss step %d" % (case, s))
+        _ndiv_close(pd, gold[2], "%s pair_div step %d" % (case, s))
+        _close(tr.action_hat[:flat * k], ref["action_hat"], 1e-4, "action_hat step %d" % s)
+        gp, dp = teacher.params()
+        gs = max(v.abs().max().item() for v in ref["g_grads"].values())
+        ds_ = max(v.abs().max().item() for v in ref["d_grads"].values())
+        _params_close(tr.g_flat, _flat(gp), _flat(ref["g_grads"]), gs, lr, "G params step %d" % s)
+        if dsteps == 1:
+            _params_close(tr.d_flat, _flat(dp), _flat(ref["d_grads"]), ds_, lr, "D params step %d" % s)
+        else:
+            assert (tr.d_flat.cpu() - _flat(dp)).abs().max().item() <= 2.5 * lr * dsteps
+    return tr
+
+
+@pytest.mark.parametrize("case", ["step_tiny_full", "step_cfg1", "step_dsteps2_nz5", "step_k32"])
+def test_trainer_teacher_forced_eager(case):
+    _teacher_forced_run(case, use_graph=False)
+
+
+@pytest.mark.parametrize("case", ["step_cfg1", "step_dsteps2_nz5"])
+def test_trainer_teacher_forced_graph(case):
+    _teacher_forced_run(case, use_graph=True)
+
+
+def test_trainer_gradients_match_golden():
+    """Non-fused mode exposes the gradients: compare with the reference's autograd grads."""
+    from ndivplanning_amd.trainer import GanTrainer
+    rec = load_golden("step_tiny_full")
+    g, d = golden_params(rec, "g0."), golden_params(rec, "d0.")
+    dec, dis = _load_modules(g, d, 2)
+    codes = torch.from_numpy(rec["codes"]).to(DEV)
+    actions = torch.from_numpy(rec["actions"]).to(DEV)
+    noise = torch.from_numpy(rec["noise"][0]).to(DEV)
+    seen = []
+    tr = GanTrainer(dec, dis, flat=codes.shape[0], num_sample=noise.shape[1], use_graph=False,
+                    reduce_fn=lambda grad: seen.append(grad.clone()))
+    tr.step(codes, actions, noise)
+    dgold = torch.cat([torch.from_numpy(rec["s0.dgrad." + n]).reshape(-1) for n, _ in dis.named_parameters()])
+    ggold = torch.cat([torch.from_numpy(rec["s0.ggrad." + n]).reshape(-1) for n, _ in dec.named_parameters()])
+    _close(seen[0], dgold, 1e-5 * max(1.0, dgold.abs().max().item()), "D gradient")
+    _close(seen[1], ggold, 1e-5 * max(1.0, ggold.abs().max().item()), "G gradient")
+    _close(tr.g_flat, _flat(golden_params(rec, "s0.g.")), 2.5 * 2e-4, "G params")
+
+
+def test_graph_replay_is_bitwise_eager():
+    from ndivplanning_amd.trainer import GanTrainer
+    codes, actions, noise = O.synthetic_batch(3, 16, 6, steps=4)
+    outs = []
+    for use_graph in (False, True):
+        g, d = O.init_params(0, 2)
+        dec, dis = _load_modules(g, d, 2)
+        tr = GanTrainer(dec, dis, flat=codes.shape[0], num_sample=6, use_graph=use_graph)
+        for s in range(4):
+            tr.step(codes.to(DEV), actions.to(DEV), noise[s].to(DEV))
+        outs.append((tr.g_flat.clone(), tr.d_flat.clone(), tr.losses()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][2] == outs[1][2]
+
+
+@pytest.mark.parametrize("batch,k", [(64, 6), (128, 32), (5, 7)])
+def test_free_running_vs_oracle(batch, k):
+    """Free-running (no forcing) for 3 steps at BASELINE shapes: BCE losses stay within
+    1e-4; NDiv within the free-running bound (Adam amplifies summation-order noise, see
+    tests/test_oracle_golden.py)."""
+    from ndivplanning_amd.trainer import GanTrainer
+    codes, actions, noise = O.synthetic_batch(7, batch, k, steps=3)
+    g, d = O.init_params(0, 2)
+    sm = O.StepMath({n: v.clone() for n, v in g.items()}, {n: v.clone() for n, v in d.items()})
+    dec, dis = _load_modules(g, d, 2)
+    tr = GanTrainer(dec, dis, flat=codes.shape[0], num_sample=k)
+    for s in range(3):
+        ref = sm.step(codes, actions, noise[s])
+        tr.step(codes.to(DEV), actions.to(DEV), noise[s].to(DEV))
+        d_loss, g_loss, pd = tr.losses()
+        _close(d_loss, ref["d_loss"], 1e-4, "D_loss step %d" % s)
+        _close(g_loss, ref["g_loss"], 1e-4, "G_loss step %d" % s)
+        if s == 0:
+            _ndiv_close(pd, ref["pair_div"].item(), "pair_div")
+            _close(tr.action_hat[:codes.shape[0] * k], ref["action_hat"], 1e-4, "action_hat")
+        else:
+            assert abs(pd - ref["pair_div"].item()) <= 2e-2 * abs(ref["pair_div"].item())
+
+
+def test_data_parallel_two_shards_equal_global_batch():
+    """Two trainers, each with half of the rows and inv_m of the GLOBAL batch, gradients
+    summed between phases (what the RCCL all-reduce does), equal one trainer on the whole
+    batch: BCE is a mean (global count), NDiv a sum."""
+    from ndivplanning_amd.trainer import GanTrainer
+    batch, k = 16, 6
+    codes, actions, noise = O.synthetic_batch(11, batch, k, steps=2)
+    flat = codes.shape[0]
+    half = flat // 2
+    g, d = O.init_params(0, 2)
+    dec, dis = _load_modules(g, d, 2)
+    whole = GanTrainer(dec, dis, flat=flat, num_sample=k, use_graph=False)
+    ranks = []
+    for r in range(2):
+        dr, di = _load_modules(g, d, 2)
+        ranks.append(GanTrainer(dr, di, flat=half, num_sample=k, flat_global=flat, use_graph=False,
+                                reduce_fn=lambda grad: None))
+    for s in range(2):
+        whole.step(codes.to(DEV), actions.to(DEV), noise[s].to(DEV))
+        for r, t in enumerate(ranks):
+            sl = slice(r * half, (r + 1) * half)
+            t.codes.copy_(codes[sl])
+            t.actions.copy_(actions[sl])
+            t.noise.copy_(noise[s][sl])
+        segs = [t._segments(False) for t in ranks]
+        for i in range(len(segs[0])):
+            for r in range(2):
+                segs[r][i][0]()
+            if segs[0][i][1] is not None:
+                total = segs[0][i][1] + segs[1][i][1]
+                for r in range(2):
+                    segs[r][i][1].copy_(total)
+        for t in ranks:
+            _close(t.g_flat, whole.g_flat, 2e-6, "G params rank vs whole, step %d" % s)
+            _close(t.d_flat, whole.d_flat, 2e-6, "D params rank vs whole, step %d" % s)
+        lw = whole.losses()
+        lsum = [ranks[0].losses()[i] + ranks[1].losses()[i] for i in range(3)]
+        _close(lsum[0], lw[0], 1e-5, "D_loss shares")
+        _close(lsum[1], lw[1], 1e-5, "G_loss shares")
+        _ndiv_close(lsum[2], lw[2], "pair_div shares")
+
+
+def test_adam_kernel_matches_oracle():
+    from ndivplanning_amd import _capi
+    lib = _capi.load()
+    gen = torch.Generator().manual_seed(5)
+    n = 58305
+    p = torch.randn(n, generator=gen)
+    ref = {"w": p.clone()}
+    opt = O.AdamState(ref, 2e-4)
+    pd_, m, v = p.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for t in range(5):
+        gr = torch.randn(n, generator=gen) * (10.0 ** -t)
+        opt.apply(ref, {"w": gr})
+        grd = gr.to(DEV)
+        _capi.check(lib.ndp_adam_step(_capi.ptr(pd_), _capi.ptr(grd), _capi.ptr(m), _capi.ptr(v), n, _capi.ptr(step),
+                                      2e-4, 0.5, 0.999, 1e-8, _capi.stream_ptr()), "adam")
+        _close(pd_, ref["w"], 2e-6, "params after %d Adam steps" % (t + 1))
+    assert int(step.item()) == 5
+
+
+def test_device_noise_is_uniform_and_counter_based():
+    from ndivplanning_amd import _capi
+    lib = _capi.load()
+    n = 1 << 20
+    out = torch.empty(n, device=DEV)
+    ctr = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _capi.check(lib.ndp_uniform_noise(_capi.ptr(out), n, 123, _capi.ptr(ctr), _capi.stream_ptr()), "noise")
+    a = out.clone()
+    assert 0.0 <= a.min().item() and a.max().item() < 1.0
+    assert abs(a.mean().item() - 0.5) < 2e-3 and abs(a.var().item() - 1 / 12) < 2e-3
+    _capi.check(lib.ndp_uniform_noise(_capi.ptr(out), n, 123, _capi.ptr(ctr), _capi.stream_ptr()), "noise")
+    assert torch.equal(a, out)
+    ctr.fill_(1)
+    _capi.check(lib.ndp_uniform_noise(_capi.ptr(out), n, 123, _capi.ptr(ctr), _capi.stream_ptr()), "noise")
+    assert not torch.equal(a, out)
