@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- GAN train steps/sec of the HIP path on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one iteration of the reference's train_gan.py loop body (train_gan.py:159-203:
+one D update + one G update) on one synthetic codes-mode batch, BASELINE config 2:
+B = 64 trajectories, traj_len = 8 (FLAT = 448 rows), K = 6 samples (M = 2,688 rows), nz = 2.
+Inputs (codes, actions) are resident in HBM; the K noise samples are drawn per step on the
+device inside the timed region; nothing is skipped (both Adam updates, all three losses).
+
+N > 1 is weak scaling: every rank trains its own 64-trajectory shard of a global batch of
+64*N (gradients summed by one RCCL all-reduce per network per step), so `value` counts
+batch-64 steps: N * iterations/s.
+
+Rank 0 prints one JSON line (contract in the task statement) with two extra objects:
+  roofline     the dominant kernel of the step vs the fp32-MFMA peak (157.3 TFLOP/s):
+               algorithmic FLOPs of that kernel per launch / its average duration, measured
+               with HIP events on the launch stream (ndp_timing_*), plus every kernel's share;
+  cpu_baseline the oracle's restated reference loop (torch CPU fp32) timed on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
+HBM_PEAK_GBS = 8000.0
+
+# algorithmic MACs per M-row of each kernel (629,760 per row per step)
+G_FWD = 128 * 258 + 64 * 128 + 128 * 64 + 256 * 128 + 4 * 256           # 83,200
+D_FWD = 64 * 260 + 128 * 64 + 256 * 128 + 256                            # 57,856
+D_DGRAD = 256 + 256 * 128 + 128 * 64                                     # 41,216
+G_DGRAD = 4 * 256 + 256 * 128 + 128 * 64 + 64 * 128                      # 50,176
+KERNEL_MACS_PER_ROW = {
+    "k_g_fwd": G_FWD,
+    "k_d[2 pass fwd+bwd]": 2 * (D_FWD + D_DGRAD),
+    "k_wgrad[D]": 2 * D_FWD,
+    "k_d[fwd+bwd]": D_FWD + D_DGRAD + 4 * 64,
+    "k_g_bwd": G_DGRAD,
+    "k_wgrad[G]": G_FWD,
+}
+assert sum(KERNEL_MACS_PER_ROW.values()) == 629760
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--batch", type=int, default=64, help="trajectories per GPU (BASELINE config 2: 64)")
+    ap.add_argument("--num-sample", type=int, default=6)
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(batch, k, nz, seconds):
+    """The reference arithmetic (oracle.AutogradTrainer: the restated train_gan.py loop on
+    torch CPU fp32) timed on this host's cores: a bounded sample of the same workload."""
+    from oracle import gan_oracle as O
+    threads = torch.get_num_threads()
+    g, d = O.init_params(0, nz)
+    codes, actions, noise = O.synthetic_batch(0, batch, k, nz, steps=8)
+    tr = O.AutogradTrainer(g, d)
+    for s in range(3):
+        tr.step(codes, actions, noise[s % 8])
+    n, t0 = 0, time.perf_counter()
+    while True:
+        tr.step(codes, actions, noise[n % 8])
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 5000:
+            break
+    return {"value": round(n / dt, 3), "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": "%d steps of the same B=%d,K=%d codes-mode workload in %.1f s (torch %s CPU fp32, %d threads)"
+                      % (n, batch, k, dt, torch.__version__, threads)}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs a torch.distributed.run launch with that many ranks" % args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path exists)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    reduce_fn = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+        def reduce_fn(grad):
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+
+    from ndivplanning_amd import _capi
+    from ndivplanning_amd.models.gan import Decoder, Discriminator
+    from ndivplanning_amd.trainer import GanTrainer
+    from oracle import gan_oracle as O   # inputs + the step-0 parity figure + cpu_baseline only
+
+    batch, k, nz, traj = args.batch, args.num_sample, 2, 8
+    flat = batch * (traj - 1)
+    m = flat * k
+    g, d = O.init_params(0, nz)
+    dec, dis = Decoder(nz), Discriminator()
+    dec.load_state_dict(g)
+    dis.load_state_dict(d)
+    dec, dis = dec.to(dev), dis.to(dev)
+    codes, actions, noise = O.synthetic_batch(1000 + rank, batch, k, nz, steps=1)
+    tr = GanTrainer(dec, dis, flat=flat, num_sample=k, flat_global=flat * world, reduce_fn=reduce_fn,
+                    use_graph=not args.no_graph, noise_seed=rank)
+
+    # step-0 parity figure (outside the timed region): NDiv / losses vs the oracle on rank 0's shard
+    parity = None
+    if world == 1:
+        ref = O.StepMath({n_: v.clone() for n_, v in g.items()}, {n_: v.clone() for n_, v in d.items()})
+        out = ref.step(codes, actions, noise[0])
+        tr.step(codes.to(dev), actions.to(dev), noise[0].to(dev))
+        dl, gl, pd = tr.losses()
+        parity = {"ndiv_rel_err": abs(pd - out["pair_div"].item()) / max(1.0, abs(out["pair_div"].item())),
+                  "d_loss_abs_err": abs(dl - out["d_loss"].item()), "g_loss_abs_err": abs(gl - out["g_loss"].item()),
+                  "action_hat_max_abs_err": (tr.action_hat[:m].cpu() - out["action_hat"]).abs().max().item()}
+    else:
+        tr.codes.copy_(codes)
+        tr.actions.copy_(actions)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        tr.step()                      # device noise, resident inputs
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    losses = tr.losses()
+
+    # per-kernel durations: HIP events around every launch, eager launches of the same step
+    kernels = {}
+    if rank == 0:
+        saved = tr.use_graph
+        tr.use_graph = False
+        _capi.timing_enable(True)
+        reps = 50
+        for _ in range(reps):
+            tr.step()
+        torch.cuda.synchronize(dev)
+        timed = _capi.timing_collect()
+        _capi.timing_enable(False)
+        tr.use_graph = saved
+        for name, (ms, cnt) in timed.items():
+            us = 1e3 * ms / max(cnt, 1)
+            macs = KERNEL_MACS_PER_ROW.get(name)
+            kernels[name] = {"avg_us": round(us, 3), "launches_per_step": cnt / reps,
+                             "tflops": round(2.0 * macs * m / (us * 1e-6) / 1e12, 3) if macs else None}
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    iters_per_s = args.steps / elapsed
+    value = iters_per_s * world
+    dom = max((n_ for n_ in kernels if KERNEL_MACS_PER_ROW.get(n_)), key=lambda n_: kernels[n_]["avg_us"] * kernels[n_]["launches_per_step"])
+    dom_flops = 2.0 * KERNEL_MACS_PER_ROW[dom] * m
+    achieved = dom_flops / (kernels[dom]["avg_us"] * 1e-6) / 1e12
+    step_flops = 2.0 * 629760 * m
+    result = {
+        "metric": "gan_train_steps_per_sec_traj8_batch64", "value": round(value, 2), "unit": "steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 5), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: train_gan.py step (D update + G update), codes mode, "
+                               "batch=%d trajectories per GPU, traj_len=8, num_sample=%d, noise_dim=2" % (batch, k),
+                   "rows_per_gpu": m, "global_batch": batch * world, "parallelism": "dp%d" % world,
+                   "trajectories_per_sec": round(iters_per_s * batch * world, 1),
+                   "hip_graph": not args.no_graph, "last_losses": {"D": losses[0], "G": losses[1], "ndiv": losses[2]}},
+        "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                     "algorithmic_flops_per_launch": dom_flops,
+                     "whole_step": {"flops": step_flops,
+                                    "tflops": round(step_flops * iters_per_s / 1e12, 3),
+                                    "frac": round(step_flops * iters_per_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)},
+                     "kernels": kernels},
+    }
+    if parity is not None:
+        result["parity_step0"] = {k_: float("%.3e" % v) for k_, v in parity.items()}
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(batch, k, nz, args.cpu_seconds)
+        result["cpu_baseline"]["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
+    print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -198,6 +198,18 @@ int ndp_step_g_grads(const ndp_step_config *cfg, const ndp_step_buffers *buf,
 int ndp_uniform_noise(float *out, int64_t n, uint64_t seed, const int32_t *offset_dev,
                       void *stream);
 
+/* ------------------------------------------------------------ measurement ---
+ * Per-kernel timing for bench.py: while enabled (per host thread) every kernel
+ * this library launches is bracketed by hipEvents recorded on the stream it is
+ * launched on.  Must be off during graph capture.
+ * ndp_timing_collect synchronises on the recorded events, sums the elapsed ms
+ * per kernel name and resets the record: names receives "name0;name1;..."
+ * (at most names_len bytes), total_ms / counts up to max_kernels entries.
+ * Returns the number of distinct kernels; 0 with ndp_last_error() set on failure. */
+int ndp_timing_enable(int on);
+int ndp_timing_collect(char *names, int names_len, float *total_ms, int32_t *counts,
+                       int max_kernels);
+
 #ifdef __cplusplus
 }
 #endif

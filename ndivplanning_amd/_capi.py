@@ -69,6 +69,8 @@ SIGNATURES = {
     "ndp_step_g_grads": (c_int, [POINTER(StepConfig), POINTER(StepBuffers), c_void_p, c_void_p, c_void_p,
                                  c_void_p]),
     "ndp_uniform_noise": (c_int, [c_void_p, c_int64, c_uint64, c_void_p, c_void_p]),
+    "ndp_timing_enable": (c_int, [c_int]),
+    "ndp_timing_collect": (c_int, [ctypes.c_char_p, c_int, POINTER(c_float), POINTER(c_int32), c_int]),
 }
 
 
@@ -122,6 +124,21 @@ def require_gpu_f32(t, name):
 
 def empty(n, like):
     return torch.empty(int(n), dtype=torch.float32, device=like.device)
+
+
+def timing_enable(on):
+    load().ndp_timing_enable(1 if on else 0)
+
+
+def timing_collect():
+    """{kernel name: (total ms, launches)} since timing was enabled / last collected."""
+    lib = load()
+    names = ctypes.create_string_buffer(2048)
+    ms = (c_float * 32)()
+    counts = (c_int32 * 32)()
+    n = lib.ndp_timing_collect(names, 2048, ms, counts, 32)
+    keys = [k for k in names.value.decode().split(";") if k]
+    return {keys[i]: (float(ms[i]), int(counts[i])) for i in range(min(n, len(keys)))}
 
 
 def g_param_count(noise_dim):
