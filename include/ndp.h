@@ -132,8 +132,10 @@ int ndp_d_backward(const float *d_params,
 /* ----------------------------------------------------------------- Adam ---
  * torch.optim.Adam.step for one flat parameter vector (train_gan.py:98-104,
  * 184, 203): m += (1-b1)(g-m); v = b2 v + (1-b2) g^2;
- * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),  t = *step_count + 1.
- * step_count is a DEVICE int32 that the call increments (after use), so that a
+ * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),  t = step_count[0] + 1.
+ * step_count is a DEVICE int32[4] "Adam state word": [0] = number of updates applied
+ * so far (the call increments it), [1..3] = scratch owned by the library (the bias
+ * corrections of the current update, computed once on the device in fp64), so that a
  * captured graph replays with the right bias correction. */
 int ndp_adam_step(float *params, const float *grad, float *exp_avg, float *exp_avg_sq,
                   int64_t n, int32_t *step_count, float lr, float beta1, float beta2,
@@ -166,14 +168,15 @@ typedef struct ndp_step_config {
   float   pairwise_div_factor; /* training.gan.pairwise_div_factor */
   float   lr, beta1, beta2, eps;
   int32_t fuse_adam;           /* 1: apply Adam inside the phase; 0: leave grads */
-  int32_t reserved;
+  int32_t device_noise;        /* 1: G forward draws the noise itself (see `noise` below) */
+  uint64_t noise_seed;         /* stream id of the device noise (e.g. the rank) */
 } ndp_step_config;
 
 /* Caller-owned persistent state of one trainer (all device memory). */
 typedef struct ndp_step_buffers {
   float   *g_params, *g_grad, *g_exp_avg, *g_exp_avg_sq;   /* [ndp_g_param_count] */
   float   *d_params, *d_grad, *d_exp_avg, *d_exp_avg_sq;   /* [ndp_d_param_count] */
-  int32_t *g_step, *d_step;                                 /* Adam step counts */
+  int32_t *g_step, *d_step;                                 /* Adam state words, int32[4] each */
   float   *losses;       /* [4]: D_loss, G_loss, pair_div (local shares), unused */
   float   *loss_sums;    /* [4]: running sums of the above (epoch averages) or NULL */
   float   *action_hat;   /* [pad(M), 4] generated actions of the current step */
@@ -184,17 +187,20 @@ int64_t ndp_step_workspace_floats(const ndp_step_config *cfg);
 
 /* codes [flat,256], actions [flat,4] (ground truth), noise [flat,K,nz].
  * run_g_forward: 1 on the first D step of an iteration, 0 on repeats
- * (discrim_steps_per_gen > 1 re-uses action_hat, train_gan.py:172). */
+ * (discrim_steps_per_gen > 1 re-uses action_hat, train_gan.py:172).
+ * With cfg->device_noise the G forward fills `noise` itself with U[0,1) drawn from the
+ * counter-based stream (noise_seed, offset = g_step[0]) -- the torch.FloatTensor(...)
+ * .uniform_() of diverse_sampling (train_gan.py:44) without the host round trip -- and
+ * the later kernels read it from there; otherwise `noise` is an input. */
 int ndp_step_d_grads(const ndp_step_config *cfg, const ndp_step_buffers *buf,
-                     const float *codes, const float *actions, const float *noise,
+                     const float *codes, const float *actions, float *noise,
                      int run_g_forward, void *stream);
 int ndp_step_g_grads(const ndp_step_config *cfg, const ndp_step_buffers *buf,
                      const float *codes, const float *actions, const float *noise,
                      void *stream);
 
-/* Device-side uniform noise U[0,1) for diverse_sampling (train_gan.py:44) when
- * the caller does not need the reference's CPU random stream: counter-based
- * (Philox-4x32-10), element i of call `offset` depends only on (seed, offset, i). */
+/* The same device noise stream as a stand-alone call: out[i] = U[0,1) from
+ * Philox-4x32-10 keyed by seed, counter (i/4, *offset_dev), word i%4. */
 int ndp_uniform_noise(float *out, int64_t n, uint64_t seed, const int32_t *offset_dev,
                       void *stream);
 

@@ -30,7 +30,7 @@ class StepConfig(Structure):
     _fields_ = [("noise_dim", c_int32), ("num_sample", c_int32), ("flat", c_int64),
                 ("inv_m_global", c_float), ("pairwise_div_factor", c_float),
                 ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
-                ("fuse_adam", c_int32), ("reserved", c_int32)]
+                ("fuse_adam", c_int32), ("device_noise", c_int32), ("noise_seed", c_uint64)]
 
 
 class StepBuffers(Structure):

@@ -22,6 +22,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef NDP_ROTATE_K
+#define NDP_ROTATE_K 1
+#endif
+
 namespace ndp {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -51,12 +55,28 @@ __device__ __forceinline__ float act_bwd(float h, float g) {
   return g;
 }
 
+// Scheduling fence that global loads may not cross (everything else may): hipcc otherwise
+// sinks prefetch loads back down to just ahead of their first use, which re-exposes the
+// L2 latency the prefetch ring is there to hide.  MFMAs may not cross either (or the compiler
+// hoists the consumers up between the prefetch loads instead).  Mask = all but VMEM and MFMA
+// (LLVM SchedGroupMask: ALU 1, VALU 2, SALU 4, MFMA 8, VMEM 0x10/0x20/0x40, DS 0x80/0x100/0x200, TRANS 0x400).
+__device__ __forceinline__ void pin_vmem() { __builtin_amdgcn_sched_barrier(0x0786); }
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+#ifdef NDP_EXP_NOMFMA     // diagnostic ablation: keep operands live, drop the matrix op
+  c[0] += a * b;
+  return c;
+#else
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
 }
 
 template <int WALIGN>
 __device__ __forceinline__ f32x4 ldg4(const float* p) {
+#ifdef NDP_EXP_NOLOAD     // diagnostic ablation: no weight traffic
+  const float v = (float)(reinterpret_cast<uintptr_t>(p) & 1023) * 1e-3f;
+  return f32x4{v, v + 1.f, v + 2.f, v + 3.f};
+#endif
   if (WALIGN >= 4) {
     return *reinterpret_cast<const f32x4*>(p);
   } else {
@@ -98,13 +118,57 @@ __device__ __forceinline__ void layer_fwd(const float* X, int ldx,
   const float* wp = Wm + (size_t)(col0 + c) * ldw + 4 * q;
   const float* xp = X + c * ldx + 4 * q;
 
+  // epilogue operand (bias) and the "tail" weight columns are fetched first so that their
+  // latency hides under the main loop.  The tail (<= 16 extra inputs: noise / action) is one
+  // more 16-wide k-step with masked weights; Xt rows are zero-padded to 16 in LDS.
+  float bias_r[NT];
+  f32x4 wtail[NT];
 #pragma unroll
-  for (int k0 = 0; k0 < IN; k0 += 16) {
+  for (int n = 0; n < NT; ++n) {
+    const int col = col0 + n * 16 + c;
+    bias_r[n] = bias[col];
+    wtail[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (Xt != nullptr) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * q + j < tail_n) wtail[n][j] = Wt[(size_t)col * ldw + 4 * q + j];
+    }
+  }
+
+  // Weight fragments are prefetched PF k-steps ahead in a register ring: the loop is fully
+  // unrolled, so ring slots are static registers and each load is issued ~PF*4*RT*NT MFMAs
+  // (>= 1,000 cycles) before its use -- an L2 / Infinity-Cache hit costs 500-900 cycles.
+  constexpr int NIT = IN / 16;
+  constexpr int PF0 = 96 / (4 * NT);
+  constexpr int PF = PF0 < NIT ? PF0 : NIT;
+  // every workgroup walks the reduction in a different rotation, so that the workgroups of an
+  // XCD (which all read the same weights) do not hit the same L2 lines at the same moment
+  const int rot = NDP_ROTATE_K ? (int)((blockIdx.x + blockIdx.y * 5) % NIT) : 0;
+  auto koff = [&](int t) { return 16 * ((t + rot) % NIT); };
+  f32x4 ring[PF][NT];
+#ifdef NDP_EXP_CONTIG   // diagnostic: same bytes, lane-contiguous 1 KiB per wave-load (wrong results)
+  auto waddr = [&](int n, int t) { return Wm + ((size_t)((wave * NT + n) * NIT + t) * 64 + lane) * 4; };
+#else
+  auto waddr = [&](int n, int t) { return wp + (size_t)(n * 16) * ldw + koff(t); };
+#endif
+#pragma unroll
+  for (int p = 0; p < PF; ++p)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) ring[p][n] = ldg4<WALIGN>(waddr(n, p));
+  pin_vmem();
+
+#pragma unroll
+  for (int t = 0; t < NIT; ++t) {
     f32x4 bv[NT], av[RT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) bv[n] = ldg4<WALIGN>(wp + (size_t)(n * 16) * ldw + k0);
+    for (int n = 0; n < NT; ++n) bv[n] = ring[t % PF][n];
+    if (t + PF < NIT) {
 #pragma unroll
-    for (int r = 0; r < RT; ++r) av[r] = *reinterpret_cast<const f32x4*>(xp + r * 16 * ldx + k0);
+      for (int n = 0; n < NT; ++n) ring[t % PF][n] = ldg4<WALIGN>(waddr(n, t + PF));
+      pin_vmem();
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) av[r] = *reinterpret_cast<const f32x4*>(xp + r * 16 * ldx + koff(t));
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -113,25 +177,27 @@ __device__ __forceinline__ void layer_fwd(const float* X, int ldx,
         for (int n = 0; n < NT; ++n) acc[r][n] = mfma16(av[r][s], bv[n][s], acc[r][n]);
   }
 
+  if (Xt != nullptr) {
+    f32x4 at[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) at[r] = *reinterpret_cast<const f32x4*>(Xt + (r * 16 + c) * ldt + 4 * q);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[r][n] = mfma16(at[r][s], wtail[n][s], acc[r][n]);
+  }
+
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int col = col0 + n * 16 + c;
-    const float b = bias[col];
-    float wt[16];
-    if (Xt != nullptr) {
-#pragma unroll
-      for (int t = 0; t < 16; ++t) wt[t] = t < tail_n ? Wt[(size_t)col * ldw + t] : 0.f;
-    }
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = r * 16 + 4 * q + i;
-        float v = acc[r][n][i] + b;
-        if (Xt != nullptr) {
-          for (int t = 0; t < tail_n; ++t) v = fmaf(Xt[row * ldt + t], wt[t], v);
-        }
-        Y[row * ldy + col] = act_fwd<ACT>(v);
+        Y[row * ldy + col] = act_fwd<ACT>(acc[r][n][i] + bias_r[n]);
       }
   }
 }
@@ -162,23 +228,41 @@ __device__ __forceinline__ void layer_dgrad(const float* dY, int ldd,
   const float* wp = W + (size_t)(4 * q) * ldw + colbase;
   const float* dp = dY + c * ldd + 4 * q;
 
+  constexpr int NIT = OUT / 16;
+  constexpr int PF0 = 96 / (4 * V);
+  constexpr int PF = PF0 < NIT ? PF0 : NIT;
+  float ring[PF][4][V];
+  auto load_step = [&](int t, float (&dst)[4][V]) {
 #pragma unroll
-  for (int j0 = 0; j0 < OUT; j0 += 16) {
+    for (int s = 0; s < 4; ++s) {
+      const float* p = wp + (size_t)(16 * t + s) * ldw;
+      if (V == 2) {
+        f32x2 v2 = *reinterpret_cast<const f32x2*>(p);
+        dst[s][0] = v2[0];
+        dst[s][V - 1] = v2[1];
+      } else {
+        dst[s][0] = *p;
+      }
+    }
+  };
+#pragma unroll
+  for (int p = 0; p < PF; ++p) load_step(p, ring[p]);
+  pin_vmem();
+
+#pragma unroll
+  for (int t = 0; t < NIT; ++t) {
     float bv[4][V];
     f32x4 av[RT];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const float* p = wp + (size_t)(j0 + s) * ldw;
-      if (V == 2) {
-        f32x2 t = *reinterpret_cast<const f32x2*>(p);
-        bv[s][0] = t[0];
-        bv[s][V - 1] = t[1];
-      } else {
-        bv[s][0] = *p;
-      }
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int v = 0; v < V; ++v) bv[s][v] = ring[t % PF][s][v];
+    if (t + PF < NIT) {
+      load_step(t + PF, ring[t % PF]);
+      pin_vmem();
     }
 #pragma unroll
-    for (int r = 0; r < RT; ++r) av[r] = *reinterpret_cast<const f32x4*>(dp + r * 16 * ldd + j0);
+    for (int r = 0; r < RT; ++r) av[r] = *reinterpret_cast<const f32x4*>(dp + r * 16 * ldd + 16 * t);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -322,13 +406,17 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// Sum over the 256 threads of a workgroup; result valid in thread 0.  `red` = 4 LDS floats.
+// Sum over the threads of a workgroup (blockDim.x = 64..256); result valid in thread 0.
+// `red` = 4 LDS floats.
 __device__ __forceinline__ float block_sum(float v, float* red) {
   v = wave_sum(v);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
   float r = 0.f;
-  if (threadIdx.x == 0) r = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0) {
+    const int nw = blockDim.x >> 6;
+    for (int w = 0; w < nw; ++w) r += red[w];
+  }
   __syncthreads();
   return r;
 }

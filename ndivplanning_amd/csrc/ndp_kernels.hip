@@ -16,6 +16,33 @@
 
 namespace ndp {
 
+// Diagnostic build only (-DNDP_STAMPS, scripts/diag_stamps.py): thread 0 of every workgroup
+// records {shader clock, 100 MHz wall clock} at phase boundaries into a side buffer that no
+// kernel reads.  The shipped library contains no stamp.
+#ifdef NDP_STAMPS
+__device__ unsigned long long* g_stamps = nullptr;
+// stamps are kept in LDS (a global store per stamp would sit in the wave's vmcnt queue and
+// delay the next counted wait) and flushed by NDP_STAMP_FLUSH at the end of the kernel
+#define NDP_STAMP_DECL __shared__ unsigned long long stamp_lds_[32]
+#define NDP_STAMP(i)                                             \
+  do {                                                           \
+    if (threadIdx.x == 0) {                                      \
+      stamp_lds_[2 * (i)] = clock64();                           \
+      stamp_lds_[2 * (i) + 1] = wall_clock64();                  \
+    }                                                            \
+  } while (0)
+#define NDP_STAMP_FLUSH(n)                                                                  \
+  do {                                                                                      \
+    if (threadIdx.x == 0 && g_stamps != nullptr)                                            \
+      for (int i_ = 0; i_ < 2 * (n); ++i_)                                                  \
+        g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + i_] = stamp_lds_[i_]; \
+  } while (0)
+#else
+#define NDP_STAMP_DECL
+#define NDP_STAMP(i) do { } while (0)
+#define NDP_STAMP_FLUSH(n) do { } while (0)
+#endif
+
 constexpr int CODE = 256;
 constexpr int ADIM = 4;
 constexpr int TAILLD = 16;   // LDS row stride of the narrow "tail" inputs (noise / action)
@@ -28,6 +55,33 @@ struct DNet {
   const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;
 };
 
+// ================================================================ uniform noise (Philox-4x32-10)
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+
+// element `e` of the noise stream (seed, offset): Philox-4x32-10 block e/4, word e%4 -> U[0,1)
+__device__ __forceinline__ float philox_uniform(uint64_t e, uint64_t seed, uint32_t off) {
+  const uint64_t blk = e >> 2;
+  uint32_t c[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), off, 0x6e647021u};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  const uint32_t w = (e & 3) == 0 ? c[0] : (e & 3) == 1 ? c[1] : (e & 3) == 2 ? c[2] : c[3];
+  return (float)(w >> 8) * (1.0f / 16777216.0f);
+}
+
 // ================================================================ G forward
 struct GFwdArgs {
   GNet net;
@@ -36,6 +90,9 @@ struct GFwdArgs {
   int64_t m;
   float *h1, *h2, *h3, *h4;   // [mpad x 128/64/128/256] or all null
   float* action_hat;          // [m x 4]
+  // device noise: when noise_out != null the kernel draws U[0,1) itself (stream = seed,
+  // offset *noise_step), uses it and writes it to noise_out[m x nz] for the later kernels
+  float* noise_out; uint64_t noise_seed; const int32_t* noise_step;
 };
 
 template <int RT>
@@ -54,24 +111,41 @@ __global__ __launch_bounds__(kThreads) void k_g_fwd(GFwdArgs a) {
   float* A = H4 + R * 260;          // R x 4
   const int64_t row0 = (int64_t)blockIdx.x * R;
   const GNet& n = a.net;
+  NDP_STAMP_DECL;
+  NDP_STAMP(0);
 
   load_code_tile<RT>(Xc, 260, a.code, a.ld_code, a.code_rep, row0, a.m, a.code_vec4 != 0);
   for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {
     const int i = idx / TAILLD, t = idx % TAILLD;
     const int64_t row = row0 + i;
-    Xt[idx] = (row < a.m && t < n.nz) ? a.noise[row * a.ld_noise + t] : 0.f;
+    float v = 0.f;
+    if (row < a.m && t < n.nz) {
+      if (a.noise_out != nullptr) {
+        v = philox_uniform((uint64_t)(row * n.nz + t), a.noise_seed, (uint32_t)*a.noise_step);
+        a.noise_out[row * n.nz + t] = v;
+      } else {
+        v = a.noise[row * a.ld_noise + t];
+      }
+    }
+    Xt[idx] = v;
   }
   __syncthreads();
+  NDP_STAMP(1);
   layer_fwd<RT, 256, 128, ACT_RELU, W1ALIGN>(Xc, 260, n.w1, n.ld1, n.b1, H1, 132, Xt, TAILLD, n.nz, n.w1 + CODE);
   __syncthreads();
+  NDP_STAMP(2);
   layer_fwd<RT, 128, 64, ACT_RELU, 4>(H1, 132, n.w2, 128, n.b2, H2, 68, nullptr, 0, 0, nullptr);
   __syncthreads();
+  NDP_STAMP(3);
   layer_fwd<RT, 64, 128, ACT_RELU, 4>(H2, 68, n.w3, 64, n.b3, H3, 132, nullptr, 0, 0, nullptr);
   __syncthreads();
+  NDP_STAMP(4);
   layer_fwd<RT, 128, 256, ACT_RELU, 4>(H3, 132, n.w4, 128, n.b4, H4, 260, nullptr, 0, 0, nullptr);
   __syncthreads();
+  NDP_STAMP(5);
   layer_fwd_narrow<RT, 256, 4>(H4, 260, n.w5, n.b5, A, 4);
   __syncthreads();
+  NDP_STAMP(6);
   if (a.h1 != nullptr) {
     store_tile<RT, 128>(a.h1 + row0 * 128, 128, H1, 132);
     store_tile<RT, 64>(a.h2 + row0 * 64, 64, H2, 68);
@@ -83,9 +157,125 @@ __global__ __launch_bounds__(kThreads) void k_g_fwd(GFwdArgs a) {
     if (row < a.m)
       *reinterpret_cast<f32x4*>(a.action_hat + row * 4) = *reinterpret_cast<const f32x4*>(A + threadIdx.x * 4);
   }
+  NDP_STAMP(7);
+  NDP_STAMP_FLUSH(8);
+}
+
+// ================================================================ NDiv (diversity.py)
+// One thread per (row n, sample i); a workgroup holds G = 256/K rows in LDS.
+// Pass 1: row sums s_i = sum_j d_ij for x and z.  Pass 2: hinge terms and the gradient
+//   dL/dx_i = sum_j -(m_ij/s_i + m_ji/s_j) (x_i - x_j)/d_ij   (0 where d_ij == 0).
+struct NdivArgs {
+  const float* x; int cx; const float* z; int cz;
+  int64_t n; int k; int rows_per_block;
+  float grad_scale;
+  float* grad;         // [n*k x cx] or null
+  float* partials;     // [gridDim.x]
+};
+constexpr int kNdivMaxC = 16;
+
+// MX / MZ: compile-time bounds of the channel loops (4 / 2 for the training path: actions
+// and <= 2-d noise; 16 / 16 generic).  Stand-alone launches use blockDim.x = 64 for k <= 64
+// (one wave holds 64/k rows) else 256; fused into k_d's launch the block has 256 threads.
+template <int MX, int MZ>
+__device__ __forceinline__ void ndiv_block(const NdivArgs& a, int bidx, float* smem) {
+  const int k = a.k, cx = a.cx, cz = a.cz, G = a.rows_per_block;
+  float* xs = smem;                     // G*k*cx
+  float* zs = xs + G * k * cx;          // G*k*cz
+  float* sx = zs + G * k * cz;          // G*k
+  float* sz = sx + G * k;               // G*k
+  float* red = sz + G * k;              // 4
+  const int nthreads = blockDim.x;
+  const int64_t n0 = (int64_t)bidx * G;
+  const int64_t nrows = (a.n - n0) < G ? (a.n - n0) : G;
+  const int nact = (int)nrows * k;
+  for (int idx = threadIdx.x; idx < nact * cx; idx += nthreads) xs[idx] = a.x[n0 * k * cx + idx];
+  for (int idx = threadIdx.x; idx < nact * cz; idx += nthreads) zs[idx] = a.z[n0 * k * cz + idx];
+  __syncthreads();
+  const int t = threadIdx.x;
+  const bool on = t < nact;
+  const int g = on ? t / k : 0, i = on ? t % k : 0;
+  float xi[MX], zi[MZ];
+#pragma unroll
+  for (int d = 0; d < MX; ++d) xi[d] = (on && d < cx) ? xs[(g * k + i) * cx + d] : 0.f;
+#pragma unroll
+  for (int d = 0; d < MZ; ++d) zi[d] = (on && d < cz) ? zs[(g * k + i) * cz + d] : 0.f;
+  if (on) {
+    float ssx = 0.f, ssz = 0.f;
+    for (int j = 0; j < k; ++j) {
+      float dx2 = 0.f, dz2 = 0.f;
+#pragma unroll
+      for (int d = 0; d < MX; ++d)
+        if (d < cx) { const float e = xi[d] - xs[(g * k + j) * cx + d]; dx2 = fmaf(e, e, dx2); }
+#pragma unroll
+      for (int d = 0; d < MZ; ++d)
+        if (d < cz) { const float e = zi[d] - zs[(g * k + j) * cz + d]; dz2 = fmaf(e, e, dz2); }
+      ssx += sqrtf(dx2);
+      ssz += sqrtf(dz2);
+    }
+    sx[g * k + i] = ssx;
+    sz[g * k + i] = ssz;
+  }
+  __syncthreads();
+  float loss = 0.f;
+  if (on) {
+    const float sxi = sx[g * k + i], szi = sz[g * k + i];
+    float gr[MX];
+#pragma unroll
+    for (int d = 0; d < MX; ++d) gr[d] = 0.f;
+    for (int j = 0; j < k; ++j) {
+      float dx2 = 0.f, dz2 = 0.f;
+      float e[MX];
+#pragma unroll
+      for (int d = 0; d < MX; ++d) {
+        e[d] = 0.f;
+        if (d < cx) { e[d] = xi[d] - xs[(g * k + j) * cx + d]; dx2 = fmaf(e[d], e[d], dx2); }
+      }
+#pragma unroll
+      for (int d = 0; d < MZ; ++d)
+        if (d < cz) { const float f = zi[d] - zs[(g * k + j) * cz + d]; dz2 = fmaf(f, f, dz2); }
+      const float dx = sqrtf(dx2), dz = sqrtf(dz2);
+      const float sxj = sx[g * k + j], szj = sz[g * k + j];
+      // z_delta * 0.8 - x_delta (diversity.py:40); relu propagates NaN like torch
+      const float hij = __fsub_rn(__fmul_rn(dz / szi, 0.8f), dx / sxi);
+      const float hji = __fsub_rn(__fmul_rn(dz / szj, 0.8f), dx / sxj);
+      loss += (hij > 0.f || hij != hij) ? hij : 0.f;
+      float w = (hij > 0.f ? 1.f / sxi : 0.f) + (hji > 0.f ? 1.f / sxj : 0.f);
+      if (hij != hij || hji != hji) w = hij + hji;          // NaN propagates into the gradient
+      if (dx > 0.f) {
+        const float f = w / dx;
+#pragma unroll
+        for (int d = 0; d < MX; ++d)
+          if (d < cx) gr[d] = fmaf(-f, e[d], gr[d]);
+      } else if (w != w) {
+#pragma unroll
+        for (int d = 0; d < MX; ++d)
+          if (d < cx) gr[d] = w;
+      }
+    }
+    if (a.grad != nullptr) {
+#pragma unroll
+      for (int d = 0; d < MX; ++d)
+        if (d < cx) a.grad[(n0 * k + t) * cx + d] = a.grad_scale * gr[d];
+    }
+  }
+  const float tot = block_sum(loss, red);
+  if (threadIdx.x == 0) a.partials[bidx] = tot;
+}
+
+template <int MX, int MZ>
+__global__ __launch_bounds__(kThreads) void k_ndiv(NdivArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  ndiv_block<MX, MZ>(a, blockIdx.x, smem);
 }
 
 // ================================================================ D forward / backward
+// One workgroup = the same 16*RT rows of NP passes (NP = 2: the real and the fake batch of the
+// D step), stacked in LDS as 16*RT*NP rows, so both passes share ONE stream of D's weights
+// (the per-CU L2->L1 rate, not the MFMA rate, bounds these kernels at small M).
+// Workgroups with blockIdx.x >= ntiles (if any) are NDiv blocks riding in the same launch:
+// the NDiv loss/gradient needs only action_hat and the noise, so it runs on otherwise idle
+// CUs during the D step instead of as a kernel of its own.
 struct DPass {
   const float* action; int action_rep; float target;
 };
@@ -94,6 +284,7 @@ struct DArgs {
   DPass pass[2];
   const float* code; int64_t ld_code; int code_rep; int code_vec4;
   int64_t m, mpad;
+  int ntiles;
   const float* ext_dlogit;    // upstream dLoss/dlogit [m] (module backward) or null -> BCE
   float inv_m;                // BCE mean scale (1 / global M)
   int do_backward;
@@ -102,90 +293,138 @@ struct DArgs {
   float *dy1, *dy2, *dy3, *dl;
   float* xa;                  // [npass*mpad x 4] action inputs, for k_wgrad
   float* d_action;            // [m x 4] or null (pass 0)
-  float* loss_partials;       // [npass * ntiles] raw BCE sums, or null
+  float* loss_partials;       // [ntiles] raw BCE sums over all passes, or null
+  NdivArgs nd;                // blocks ntiles.. : NDiv (cx <= 4, cz <= 2), nd.n == 0 -> none
 };
 
-template <int RT>
-constexpr int d_lds_floats() { return 16 * RT * (260 + TAILLD + 68 + 132 + 260 + 2) + 8; }
+template <int RT, int NP>
+constexpr int d_lds_floats() { return 16 * RT * NP * (260 + TAILLD + 68 + 132 + 260 + 2) + 8; }
 
-template <int RT>
+template <int RT, int NP>
 __global__ __launch_bounds__(kThreads) void k_d(DArgs a) {
-  constexpr int R = 16 * RT;
+  constexpr int R = 16 * RT;        // rows per pass
+  constexpr int RR = R * NP;        // LDS rows
+  constexpr int RTT = RT * NP;      // 16-row tiles the layer functions see
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Xc = smem;               // R x 260
-  float* Xt = Xc + R * 260;       // R x 16   action
-  float* H1 = Xt + R * TAILLD;    // R x 68
-  float* H2 = H1 + R * 68;        // R x 132
-  float* H3 = H2 + R * 132;       // R x 260
-  float* L = H3 + R * 260;        // R        logits
-  float* DL = L + R;              // R        dLoss/dlogit
-  float* red = DL + R;            // 4 (+4 pad)
-  const int ntiles = gridDim.x;
-  const int pass = blockIdx.y;
+  if ((int)blockIdx.x >= a.ntiles) {
+    ndiv_block<4, 2>(a.nd, (int)blockIdx.x - a.ntiles, smem);
+    return;
+  }
+  float* Xc = smem;               // RR x 260
+  float* Xt = Xc + RR * 260;      // RR x 16   action
+  float* H1 = Xt + RR * TAILLD;   // RR x 68
+  float* H2 = H1 + RR * 68;       // RR x 132
+  float* H3 = H2 + RR * 132;      // RR x 260
+  float* L = H3 + RR * 260;       // RR        logits
+  float* DL = L + RR;             // RR        dLoss/dlogit
+  float* red = DL + RR;           // 4 (+4 pad)
   const int64_t row0 = (int64_t)blockIdx.x * R;
-  const int64_t grow0 = (int64_t)pass * a.mpad + row0;   // row in the [npass*mpad] buffers
   const DNet& n = a.net;
-  const DPass ps = a.pass[pass];
+  NDP_STAMP_DECL;
+  NDP_STAMP(0);
 
-  load_code_tile<RT>(Xc, 260, a.code, a.ld_code, a.code_rep, row0, a.m, a.code_vec4 != 0);
-  for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {
-    const int i = idx / TAILLD, t = idx % TAILLD;
+  // the code part of the input is the same for every pass: fetch once, write NP copies
+  for (int idx = threadIdx.x; idx < R * 64; idx += kThreads) {
+    const int i = idx >> 6, k = 4 * (idx & 63);
     const int64_t row = row0 + i;
-    Xt[idx] = (row < a.m && t < ADIM) ? ps.action[(row / ps.action_rep) * ADIM + t] : 0.f;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < a.m) {
+      const float* p = a.code + (row / a.code_rep) * a.ld_code + k;
+      if (a.code_vec4) {
+        v = *reinterpret_cast<const f32x4*>(p);
+      } else {
+        v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3];
+      }
+    }
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) *reinterpret_cast<f32x4*>(Xc + (ps * R + i) * 260 + k) = v;
+  }
+  for (int idx = threadIdx.x; idx < RR * TAILLD; idx += kThreads) {
+    const int lr = idx / TAILLD, t = idx % TAILLD;
+    const int ps = lr / R;
+    const int64_t row = row0 + (lr - ps * R);
+    const DPass& pp = a.pass[ps];
+    Xt[idx] = (row < a.m && t < ADIM) ? pp.action[(row / pp.action_rep) * ADIM + t] : 0.f;
   }
   __syncthreads();
+  NDP_STAMP(1);
   // cat([action, code]) (models/gan.py:105): weight columns 0..3 = action, 4..259 = code
-  layer_fwd<RT, 256, 64, ACT_LRELU, 4>(Xc, 260, n.w1 + ADIM, 260, n.b1, H1, 68, Xt, TAILLD, ADIM, n.w1);
+  layer_fwd<RTT, 256, 64, ACT_LRELU, 4>(Xc, 260, n.w1 + ADIM, 260, n.b1, H1, 68, Xt, TAILLD, ADIM, n.w1);
   __syncthreads();
-  layer_fwd<RT, 64, 128, ACT_LRELU, 4>(H1, 68, n.w2, 64, n.b2, H2, 132, nullptr, 0, 0, nullptr);
+  NDP_STAMP(2);
+  layer_fwd<RTT, 64, 128, ACT_LRELU, 4>(H1, 68, n.w2, 64, n.b2, H2, 132, nullptr, 0, 0, nullptr);
   __syncthreads();
-  layer_fwd<RT, 128, 256, ACT_LRELU, 4>(H2, 132, n.w3, 128, n.b3, H3, 260, nullptr, 0, 0, nullptr);
+  NDP_STAMP(3);
+  layer_fwd<RTT, 128, 256, ACT_LRELU, 4>(H2, 132, n.w3, 128, n.b3, H3, 260, nullptr, 0, 0, nullptr);
   __syncthreads();
-  layer_fwd_narrow<RT, 256, 1>(H3, 260, n.w4, n.b4, L, 1);
+  NDP_STAMP(4);
+  layer_fwd_narrow<RTT, 256, 1>(H3, 260, n.w4, n.b4, L, 1);
   __syncthreads();
+  NDP_STAMP(5);
 
   float lsum = 0.f;
-  if (threadIdx.x < R) {
-    const int64_t row = row0 + threadIdx.x;
+  if (threadIdx.x < RR) {
+    const int ps = threadIdx.x / R;
+    const int i = threadIdx.x - ps * R;
+    const int64_t row = row0 + i;
+    const float target = a.pass[ps].target;
     const float x = L[threadIdx.x];
     float dl = 0.f;
     if (row < a.m) {
       // BCEWithLogits: max(x,0) - x*y + log1p(exp(-|x|));  d/dx = sigmoid(x) - y
-      lsum = fmaxf(x, 0.f) - x * ps.target + log1pf(expf(-fabsf(x)));
+      lsum = fmaxf(x, 0.f) - x * target + log1pf(expf(-fabsf(x)));
       dl = a.ext_dlogit != nullptr ? a.ext_dlogit[row]
-                                   : (1.f / (1.f + expf(-x)) - ps.target) * a.inv_m;
-      if (a.logits != nullptr) a.logits[(int64_t)pass * a.mpad + row] = x;
+                                   : (1.f / (1.f + expf(-x)) - target) * a.inv_m;
+      if (a.logits != nullptr) a.logits[(int64_t)ps * a.mpad + row] = x;
     }
     DL[threadIdx.x] = dl;
-    if (a.dl != nullptr) a.dl[grow0 + threadIdx.x] = dl;
+    if (a.dl != nullptr) a.dl[(int64_t)ps * a.mpad + row] = dl;
   }
   if (a.loss_partials != nullptr) {
     const float tot = block_sum(lsum, red);
-    if (threadIdx.x == 0) a.loss_partials[pass * ntiles + blockIdx.x] = tot;
+    if (threadIdx.x == 0) a.loss_partials[blockIdx.x] = tot;
   }
-  if (!a.do_backward) return;
+  NDP_STAMP(6);
+  if (!a.do_backward) {
+    NDP_STAMP_FLUSH(7);
+    return;
+  }
   if (a.h1 != nullptr) {
-    store_tile<RT, 64>(a.h1 + grow0 * 64, 64, H1, 68);
-    store_tile<RT, 128>(a.h2 + grow0 * 128, 128, H2, 132);
-    store_tile<RT, 256>(a.h3 + grow0 * 256, 256, H3, 260);
-    if (threadIdx.x < R)
-      *reinterpret_cast<f32x4*>(a.xa + (grow0 + threadIdx.x) * 4) =
-          *reinterpret_cast<const f32x4*>(Xt + threadIdx.x * TAILLD);
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const int64_t g0 = (int64_t)ps * a.mpad + row0;
+      store_tile<RT, 64>(a.h1 + g0 * 64, 64, H1 + ps * R * 68, 68);
+      store_tile<RT, 128>(a.h2 + g0 * 128, 128, H2 + ps * R * 132, 132);
+      store_tile<RT, 256>(a.h3 + g0 * 256, 256, H3 + ps * R * 260, 260);
+    }
+    if (threadIdx.x < RR) {
+      const int ps = threadIdx.x / R;
+      const int64_t g = (int64_t)ps * a.mpad + row0 + (threadIdx.x - ps * R);
+      *reinterpret_cast<f32x4*>(a.xa + g * 4) = *reinterpret_cast<const f32x4*>(Xt + threadIdx.x * TAILLD);
+    }
   }
   __syncthreads();
-  layer_dgrad_narrow<RT, 256, 1, ACT_LRELU>(DL, 1, n.w4, H3, 260);          // H3 := dY3
+  NDP_STAMP(7);
+  layer_dgrad_narrow<RTT, 256, 1, ACT_LRELU>(DL, 1, n.w4, H3, 260);          // H3 := dY3
   __syncthreads();
-  layer_dgrad<RT, 128, 256, ACT_LRELU>(H3, 260, n.w3, 128, H2, 132);         // H2 := dY2
+  NDP_STAMP(8);
+  layer_dgrad<RTT, 128, 256, ACT_LRELU>(H3, 260, n.w3, 128, H2, 132);         // H2 := dY2
   __syncthreads();
-  layer_dgrad<RT, 64, 128, ACT_LRELU>(H2, 132, n.w2, 64, H1, 68);            // H1 := dY1
+  NDP_STAMP(9);
+  layer_dgrad<RTT, 64, 128, ACT_LRELU>(H2, 132, n.w2, 64, H1, 68);            // H1 := dY1
   __syncthreads();
+  NDP_STAMP(10);
   if (a.dy1 != nullptr) {
-    store_tile<RT, 64>(a.dy1 + grow0 * 64, 64, H1, 68);
-    store_tile<RT, 128>(a.dy2 + grow0 * 128, 128, H2, 132);
-    store_tile<RT, 256>(a.dy3 + grow0 * 256, 256, H3, 260);
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const int64_t g0 = (int64_t)ps * a.mpad + row0;
+      store_tile<RT, 64>(a.dy1 + g0 * 64, 64, H1 + ps * R * 68, 68);
+      store_tile<RT, 128>(a.dy2 + g0 * 128, 128, H2 + ps * R * 132, 132);
+      store_tile<RT, 256>(a.dy3 + g0 * 256, 256, H3 + ps * R * 260, 260);
+    }
   }
-  if (a.d_action != nullptr && pass == 0 && threadIdx.x < R * ADIM) {
-    // dLoss/d action = dY1 . W1[:, 0:4]
+  if (a.d_action != nullptr && threadIdx.x < R * ADIM) {
+    // dLoss/d action = dY1 . W1[:, 0:4]   (pass 0)
     const int i = threadIdx.x >> 2, j = threadIdx.x & 3;
     const int64_t row = row0 + i;
     float s = 0.f;
@@ -193,6 +432,8 @@ __global__ __launch_bounds__(kThreads) void k_d(DArgs a) {
     for (int o = 0; o < 64; ++o) s = fmaf(H1[i * 68 + o], n.w1[o * 260 + j], s);
     if (row < a.m) a.d_action[row * ADIM + j] = s;
   }
+  NDP_STAMP(11);
+  NDP_STAMP_FLUSH(12);
 }
 
 // ================================================================ G backward (data path)
@@ -249,6 +490,18 @@ __global__ __launch_bounds__(kThreads) void k_g_bwd(GBwdArgs a) {
   store_tile<RT, 256>(a.dy4 + row0 * 256, 256, H4, 260);
 }
 
+// Adam state word: {int32 step, float lr/(1-b1^t), float sqrt(1-b2^t), pad}.  One thread
+// advances it ahead of the kernel that applies the update, so that the fp64 pow() runs once
+// per step instead of once per workgroup.
+__device__ __forceinline__ void adam_advance(int32_t* state, float lr, float b1, float b2) {
+  const int32_t t = state[0] + 1;
+  state[0] = t;
+  const double bc1 = 1.0 - pow((double)b1, (double)t);
+  const double bc2 = 1.0 - pow((double)b2, (double)t);
+  reinterpret_cast<float*>(state)[1] = (float)((double)lr / bc1);
+  reinterpret_cast<float*>(state)[2] = (float)sqrt(bc2);
+}
+
 // ================================================================ weight gradients
 // One job = one block of one layer's dW = sum_rows dY[row][j] * X[row][k]:
 //   FULL      64 j x 64 k, both operands read as float4 (j = 4c+u, k = 4c+v permuted tiles)
@@ -277,12 +530,19 @@ struct WgradArgs {
   int rows_per_chunk;  // multiple of 16
   float* slabs;        // [nchunks][slab_stride]
   int64_t slab_stride;
-  int32_t* bump;       // Adam step counter to increment (block 0,0), or null
+  int32_t* bump;       // Adam state {int32 step; float step_size; float bc2_sqrt; pad} to advance, or null
+  float lr, beta1, beta2;
 };
+
+#ifdef NDP_STAMPS
+#define NDP_WSTAMP(i) do { if (threadIdx.x == 0) { wst[2 * (i)] = clock64(); wst[2 * (i) + 1] = wall_clock64(); } } while (0)
+#else
+#define NDP_WSTAMP(i) do { } while (0)
+#endif
 
 template <int MT, int NT, int KIND>
 __device__ __forceinline__ void wgrad_block(const WgradJob& jb, int rbeg, int rend,
-                                            float* slab, float* smem) {
+                                            float* slab, float* smem, unsigned long long* wst) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
   f32x4 acc[MT][NT];
@@ -293,39 +553,69 @@ __device__ __forceinline__ void wgrad_block(const WgradJob& jb, int rbeg, int re
 #pragma unroll
     for (int v = 0; v < NT; ++v) acc[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-#pragma unroll 2
-  for (int i0 = rbeg + 4 * wave; i0 < rend; i0 += 16) {
-    const int row = i0 + q;
-    float av[MT], bv[NT];
-    if (KIND == WG_SKINNY_A) {
-      av[0] = c < jb.a_cols ? jb.A[(size_t)row * jb.lda + c] : 0.f;
-    } else {
-      const f32x4 t = *reinterpret_cast<const f32x4*>(jb.A + (size_t)row * jb.lda + 4 * c);
+  // rows are consumed in groups of PFG 4-row steps; the next group's operands are loaded
+  // before the current group's MFMAs (register double buffer), so ~PFG*16 MFMAs (>= 2,000
+  // cycles) cover each load's latency.
+  constexpr int PFG = 4;
+  float av[2][PFG][MT], bv[2][PFG][NT];
+  auto load_group = [&](int base, float (&ga)[PFG][MT], float (&gb)[PFG][NT]) {
 #pragma unroll
-      for (int u = 0; u < MT; ++u) av[u] = t[u];
-    }
-    int brow = (row % jb.b_rowmod) / jb.b_rowdiv;
-    brow = brow < jb.b_rowmax ? brow : jb.b_rowmax;
-    if (KIND == WG_SKINNY_B) {
-      bv[0] = c < jb.b_cols ? jb.B[(size_t)brow * jb.ldb + c] : 0.f;
-    } else {
-      const float* p = jb.B + (size_t)brow * jb.ldb + 4 * c;
-      f32x4 t;
-      if (jb.b_vec) {
-        t = *reinterpret_cast<const f32x4*>(p);
+    for (int g = 0; g < PFG; ++g) {
+      const int row = base + 16 * g + q;
+      const bool ok = base + 16 * g < rend;      // wave-uniform
+      if (KIND == WG_SKINNY_A) {
+        ga[g][0] = (ok && c < jb.a_cols) ? jb.A[(size_t)row * jb.lda + c] : 0.f;
       } else {
-        t[0] = p[0]; t[1] = p[1]; t[2] = p[2]; t[3] = p[3];
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (ok) t = *reinterpret_cast<const f32x4*>(jb.A + (size_t)row * jb.lda + 4 * c);
+#pragma unroll
+        for (int u = 0; u < MT; ++u) ga[g][u] = t[u];
       }
+      int brow = (row % jb.b_rowmod) / jb.b_rowdiv;
+      brow = brow < jb.b_rowmax ? brow : jb.b_rowmax;
+      if (KIND == WG_SKINNY_B) {
+        gb[g][0] = (ok && c < jb.b_cols) ? jb.B[(size_t)brow * jb.ldb + c] : 0.f;
+      } else {
+        const float* p = jb.B + (size_t)brow * jb.ldb + 4 * c;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+          if (jb.b_vec) {
+            t = *reinterpret_cast<const f32x4*>(p);
+          } else {
+            t[0] = p[0]; t[1] = p[1]; t[2] = p[2]; t[3] = p[3];
+          }
+        }
 #pragma unroll
-      for (int v = 0; v < NT; ++v) bv[v] = t[v];
+        for (int v = 0; v < NT; ++v) gb[g][v] = t[v];
+      }
     }
+  };
+  auto mma_group = [&](const float (&ga)[PFG][MT], const float (&gb)[PFG][NT]) {
 #pragma unroll
-    for (int u = 0; u < MT; ++u) {
-      bs[u] += av[u];
+    for (int g = 0; g < PFG; ++g)
 #pragma unroll
-      for (int v = 0; v < NT; ++v) acc[u][v] = mfma16(av[u], bv[v], acc[u][v]);
-    }
+      for (int u = 0; u < MT; ++u) {
+        bs[u] += ga[g][u];
+#pragma unroll
+        for (int v = 0; v < NT; ++v) acc[u][v] = mfma16(ga[g][u], gb[g][v], acc[u][v]);
+      }
+  };
+  int i0 = rbeg + 4 * wave;
+  NDP_WSTAMP(1);
+  load_group(i0, av[0], bv[0]);
+  pin_vmem();
+  while (i0 < rend) {
+    load_group(i0 + 16 * PFG, av[1], bv[1]);
+    pin_vmem();
+    mma_group(av[0], bv[0]);
+    i0 += 16 * PFG;
+    if (i0 >= rend) break;
+    load_group(i0 + 16 * PFG, av[0], bv[0]);
+    pin_vmem();
+    mma_group(av[1], bv[1]);
+    i0 += 16 * PFG;
   }
+  NDP_WSTAMP(2);
   // ---- cross-wave reduction through LDS: tile image [JR][KC] per wave
   constexpr int JR = KIND == WG_SKINNY_A ? 16 : 64;
   constexpr int KC = KIND == WG_SKINNY_B ? 16 : 64;
@@ -354,6 +644,7 @@ __device__ __forceinline__ void wgrad_block(const WgradJob& jb, int rbeg, int re
     if (q == 0) bsh[wave * 64 + (KIND == WG_SKINNY_A ? c : 4 * c + u)] = s;
   }
   __syncthreads();
+  NDP_WSTAMP(3);
   const int jn = jb.a_cols, kn = jb.b_cols;
   for (int e = threadIdx.x; e < JR * KC / 4; e += kThreads) {
     const int j = e / (KC / 4), k = 4 * (e % (KC / 4));
@@ -386,11 +677,23 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
   int rend = rbeg + a.rows_per_chunk;
   rend = rend < a.rows ? rend : a.rows;
   float* slab = a.slabs + (size_t)blockIdx.y * a.slab_stride;
-  if (a.bump != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.bump += 1;
+  if (a.bump != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+    adam_advance(a.bump, a.lr, a.beta1, a.beta2);
   const int kind = jb.kind;   // uniform per workgroup
-  if (kind == WG_FULL) wgrad_block<4, 4, WG_FULL>(jb, rbeg, rend, slab, smem);
-  else if (kind == WG_SKINNY_B) wgrad_block<4, 1, WG_SKINNY_B>(jb, rbeg, rend, slab, smem);
-  else wgrad_block<1, 4, WG_SKINNY_A>(jb, rbeg, rend, slab, smem);
+#ifdef NDP_STAMPS
+  __shared__ unsigned long long wst[32];
+  NDP_WSTAMP(0);
+#else
+  unsigned long long* wst = nullptr;
+#endif
+  if (kind == WG_FULL) wgrad_block<4, 4, WG_FULL>(jb, rbeg, rend, slab, smem, wst);
+  else if (kind == WG_SKINNY_B) wgrad_block<4, 1, WG_SKINNY_B>(jb, rbeg, rend, slab, smem, wst);
+  else wgrad_block<1, 4, WG_SKINNY_A>(jb, rbeg, rend, slab, smem, wst);
+#ifdef NDP_STAMPS
+  NDP_WSTAMP(4);
+  if (threadIdx.x == 0 && g_stamps != nullptr)
+    for (int i_ = 0; i_ < 10; ++i_) g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + i_] = wst[i_];
+#endif
 }
 
 // ================================================================ slab reduce + Adam + losses
@@ -401,7 +704,7 @@ struct ReduceArgs {
   const float* slabs; int nchunks; int64_t slab_stride; int64_t n;
   float* grad;                         // [n] or null
   float *params, *exp_avg, *exp_avg_sq;   // Adam (params null -> no update)
-  const int32_t* step;                 // device step count, already incremented
+  const int32_t* step;                 // Adam state word (already advanced for this step)
   float lr, beta1, beta2, eps;
   LossTerm loss[3]; int nloss;
   float* losses; float* loss_sums;
@@ -415,30 +718,26 @@ __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& 
   p = p - step_size * (m / denom);              // param.addcdiv_(exp_avg, denom, -step_size)
 }
 
-__device__ __forceinline__ void adam_scalars(const int32_t* step, float lr, float b1, float b2,
-                                             float* sh, float& step_size, float& bc2_sqrt) {
-  if (threadIdx.x == 0) {
-    const double t = (double)*step;
-    const double bc1 = 1.0 - pow((double)b1, t);
-    const double bc2 = 1.0 - pow((double)b2, t);
-    sh[0] = (float)((double)lr / bc1);
-    sh[1] = (float)sqrt(bc2);
-  }
-  __syncthreads();
-  step_size = sh[0];
-  bc2_sqrt = sh[1];
-}
-
 __global__ __launch_bounds__(kThreads) void k_reduce_adam(ReduceArgs a) {
   __shared__ float sh[8];
-  float step_size = 0.f, bc2_sqrt = 1.f;
-  if (a.params != nullptr) adam_scalars(a.step, a.lr, a.beta1, a.beta2, sh, step_size, bc2_sqrt);
   const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   if (p < a.n) {
-    float g = 0.f;
-    for (int ch = 0; ch < a.nchunks; ++ch) g += a.slabs[(size_t)ch * a.slab_stride + p];
+    // fixed summation order (bitwise reproducible); four independent chains keep loads in flight
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+    const float* sp = a.slabs + p;
+    int ch = 0;
+    for (; ch + 4 <= a.nchunks; ch += 4) {
+      g0 += sp[(size_t)(ch + 0) * a.slab_stride];
+      g1 += sp[(size_t)(ch + 1) * a.slab_stride];
+      g2 += sp[(size_t)(ch + 2) * a.slab_stride];
+      g3 += sp[(size_t)(ch + 3) * a.slab_stride];
+    }
+    for (; ch < a.nchunks; ++ch) g0 += sp[(size_t)ch * a.slab_stride];
+    const float g = (g0 + g1) + (g2 + g3);
     if (a.grad != nullptr) a.grad[p] = g;
     if (a.params != nullptr) {
+      const float step_size = reinterpret_cast<const float*>(a.step)[1];
+      const float bc2_sqrt = reinterpret_cast<const float*>(a.step)[2];
       float pv = a.params[p], m = a.exp_avg[p], v = a.exp_avg_sq[p];
       adam_update(pv, g, m, v, step_size, bc2_sqrt, a.beta1, a.beta2, a.eps);
       a.params[p] = pv;
@@ -461,16 +760,15 @@ __global__ __launch_bounds__(kThreads) void k_reduce_adam(ReduceArgs a) {
   }
 }
 
-__global__ void k_bump(int32_t* ctr) { *ctr += 1; }
+__global__ void k_adam_advance(int32_t* state, float lr, float b1, float b2) { adam_advance(state, lr, b1, b2); }
 
 struct AdamArgs {
   float *params, *exp_avg, *exp_avg_sq; const float* grad; int64_t n;
   const int32_t* step; float lr, beta1, beta2, eps;
 };
 __global__ __launch_bounds__(kThreads) void k_adam(AdamArgs a) {
-  __shared__ float sh[4];
-  float step_size, bc2_sqrt;
-  adam_scalars(a.step, a.lr, a.beta1, a.beta2, sh, step_size, bc2_sqrt);
+  const float step_size = reinterpret_cast<const float*>(a.step)[1];
+  const float bc2_sqrt = reinterpret_cast<const float*>(a.step)[2];
   const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   if (p < a.n) {
     float pv = a.params[p], m = a.exp_avg[p], v = a.exp_avg_sq[p];
@@ -479,102 +777,6 @@ __global__ __launch_bounds__(kThreads) void k_adam(AdamArgs a) {
     a.exp_avg[p] = m;
     a.exp_avg_sq[p] = v;
   }
-}
-
-// ================================================================ NDiv (diversity.py)
-// One thread per (row n, sample i); a workgroup holds G = 256/K rows in LDS.
-// Pass 1: row sums s_i = sum_j d_ij for x and z.  Pass 2: hinge terms and the gradient
-//   dL/dx_i = sum_j -(m_ij/s_i + m_ji/s_j) (x_i - x_j)/d_ij   (0 where d_ij == 0).
-struct NdivArgs {
-  const float* x; int cx; const float* z; int cz;
-  int64_t n; int k; int rows_per_block;
-  float grad_scale;
-  float* grad;         // [n*k x cx] or null
-  float* partials;     // [gridDim.x]
-};
-constexpr int kNdivMaxC = 16;
-
-__global__ __launch_bounds__(kThreads) void k_ndiv(NdivArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int k = a.k, cx = a.cx, cz = a.cz, G = a.rows_per_block;
-  float* xs = smem;                     // G*k*cx
-  float* zs = xs + G * k * cx;          // G*k*cz
-  float* sx = zs + G * k * cz;          // G*k
-  float* sz = sx + G * k;               // G*k
-  float* red = sz + G * k;              // 4
-  const int64_t n0 = (int64_t)blockIdx.x * G;
-  const int64_t nrows = (a.n - n0) < G ? (a.n - n0) : G;
-  const int nact = (int)nrows * k;
-  for (int idx = threadIdx.x; idx < nact * cx; idx += kThreads) xs[idx] = a.x[n0 * k * cx + idx];
-  for (int idx = threadIdx.x; idx < nact * cz; idx += kThreads) zs[idx] = a.z[n0 * k * cz + idx];
-  __syncthreads();
-  const int t = threadIdx.x;
-  const bool on = t < nact;
-  const int g = on ? t / k : 0, i = on ? t % k : 0;
-  float xi[kNdivMaxC], zi[kNdivMaxC];
-#pragma unroll
-  for (int d = 0; d < kNdivMaxC; ++d) {
-    xi[d] = (on && d < cx) ? xs[(g * k + i) * cx + d] : 0.f;
-    zi[d] = (on && d < cz) ? zs[(g * k + i) * cz + d] : 0.f;
-  }
-  if (on) {
-    float ssx = 0.f, ssz = 0.f;
-    for (int j = 0; j < k; ++j) {
-      float dx2 = 0.f, dz2 = 0.f;
-#pragma unroll
-      for (int d = 0; d < kNdivMaxC; ++d) {
-        if (d < cx) { const float e = xi[d] - xs[(g * k + j) * cx + d]; dx2 = fmaf(e, e, dx2); }
-        if (d < cz) { const float e = zi[d] - zs[(g * k + j) * cz + d]; dz2 = fmaf(e, e, dz2); }
-      }
-      ssx += sqrtf(dx2);
-      ssz += sqrtf(dz2);
-    }
-    sx[g * k + i] = ssx;
-    sz[g * k + i] = ssz;
-  }
-  __syncthreads();
-  float loss = 0.f;
-  if (on) {
-    const float sxi = sx[g * k + i], szi = sz[g * k + i];
-    float gr[kNdivMaxC];
-#pragma unroll
-    for (int d = 0; d < kNdivMaxC; ++d) gr[d] = 0.f;
-    for (int j = 0; j < k; ++j) {
-      float dx2 = 0.f, dz2 = 0.f;
-      float e[kNdivMaxC];
-#pragma unroll
-      for (int d = 0; d < kNdivMaxC; ++d) {
-        e[d] = 0.f;
-        if (d < cx) { e[d] = xi[d] - xs[(g * k + j) * cx + d]; dx2 = fmaf(e[d], e[d], dx2); }
-        if (d < cz) { const float f = zi[d] - zs[(g * k + j) * cz + d]; dz2 = fmaf(f, f, dz2); }
-      }
-      const float dx = sqrtf(dx2), dz = sqrtf(dz2);
-      const float sxj = sx[g * k + j], szj = sz[g * k + j];
-      // z_delta * 0.8 - x_delta (diversity.py:40); relu propagates NaN like torch
-      const float hij = __fsub_rn(__fmul_rn(dz / szi, 0.8f), dx / sxi);
-      const float hji = __fsub_rn(__fmul_rn(dz / szj, 0.8f), dx / sxj);
-      loss += (hij > 0.f || hij != hij) ? hij : 0.f;
-      float w = (hij > 0.f ? 1.f / sxi : 0.f) + (hji > 0.f ? 1.f / sxj : 0.f);
-      if (hij != hij || hji != hji) w = hij + hji;          // NaN propagates into the gradient
-      if (dx > 0.f) {
-        const float f = w / dx;
-#pragma unroll
-        for (int d = 0; d < kNdivMaxC; ++d)
-          if (d < cx) gr[d] = fmaf(-f, e[d], gr[d]);
-      } else if (w != w) {
-#pragma unroll
-        for (int d = 0; d < kNdivMaxC; ++d)
-          if (d < cx) gr[d] = w;
-      }
-    }
-    if (a.grad != nullptr) {
-#pragma unroll
-      for (int d = 0; d < kNdivMaxC; ++d)
-        if (d < cx) a.grad[(n0 * k + t) * cx + d] = a.grad_scale * gr[d];
-    }
-  }
-  const float tot = block_sum(loss, red);
-  if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
 }
 
 __global__ __launch_bounds__(kThreads) void k_sum_partials(const float* partials, int count,
@@ -586,33 +788,13 @@ __global__ __launch_bounds__(kThreads) void k_sum_partials(const float* partials
   if (threadIdx.x == 0) *out = s * scale;
 }
 
-// ================================================================ uniform noise (Philox-4x32-10)
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-  const uint32_t n1 = (uint32_t)p1;
-  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-  const uint32_t n3 = (uint32_t)p0;
-  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-
+// ================================================================ uniform noise kernel
 __global__ __launch_bounds__(kThreads) void k_philox(float* out, int64_t n, uint64_t seed,
                                                      const int32_t* offset_dev) {
-  const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;   // one thread = 4 floats
-  if (idx * 4 >= n) return;
+  const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= n) return;
   const uint32_t off = offset_dev != nullptr ? (uint32_t)*offset_dev : 0u;
-  uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), off, 0x6e647021u};
-  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    philox_round(c, k0, k1);
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-    if (idx * 4 + j < n) out[idx * 4 + j] = (float)(c[j] >> 8) * (1.0f / 16777216.0f);   // [0,1)
+  out[idx] = philox_uniform((uint64_t)idx, seed, off);
 }
 
 }  // namespace ndp

@@ -44,9 +44,9 @@ class GanTrainer:
         self.g_grad, self.d_grad = torch.zeros_like(self.g_flat), torch.zeros_like(self.d_flat)
         self.g_m, self.g_v = torch.zeros_like(self.g_flat), torch.zeros_like(self.g_flat)
         self.d_m, self.d_v = torch.zeros_like(self.d_flat), torch.zeros_like(self.d_flat)
-        self.g_step = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.d_step = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.noise_ctr = torch.zeros(1, dtype=torch.int32, device=dev)
+        # Adam state words (include/ndp.h): [0] = updates applied so far, [1..3] library scratch
+        self.g_step = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.d_step = torch.zeros(4, dtype=torch.int32, device=dev)
         self.losses_dev = torch.zeros(4, **f32)
         self.loss_sums = torch.zeros(4, **f32)
         mpad = _capi.pad_rows(self.m)
@@ -59,7 +59,7 @@ class GanTrainer:
             noise_dim=self.noise_dim, num_sample=self.k, flat=self.flat,
             inv_m_global=1.0 / float(self.flat_global * self.k), pairwise_div_factor=float(pairwise_div_factor),
             lr=float(lr), beta1=float(betas[0]), beta2=float(betas[1]), eps=float(eps),
-            fuse_adam=0 if reduce_fn is not None else 1, reserved=0)
+            fuse_adam=0 if reduce_fn is not None else 1, device_noise=0, noise_seed=self.noise_seed)
         nws = self.lib.ndp_step_workspace_floats(ctypes.byref(self.cfg))
         if nws <= 0:
             raise _capi.NdpError("bad step configuration (flat=%d, num_sample=%d)" % (self.flat, self.k))
@@ -78,7 +78,9 @@ class GanTrainer:
             g_step=p(self.g_step), d_step=p(self.d_step), losses=p(self.losses_dev), loss_sums=p(self.loss_sums),
             action_hat=p(self.action_hat), workspace=p(self.workspace))
 
-    def _phase_a(self, first):
+    def _phase_a(self, first, device_noise=False):
+        # device noise: the G forward kernel draws U[0,1) itself and fills self.noise
+        self.cfg.device_noise = 1 if device_noise else 0
         _capi.check(self.lib.ndp_step_d_grads(ctypes.byref(self.cfg), ctypes.byref(self.buf), _capi.ptr(self.codes),
                                               _capi.ptr(self.actions), _capi.ptr(self.noise), 1 if first else 0,
                                               _capi.stream_ptr()), "ndp_step_d_grads")
@@ -94,11 +96,6 @@ class GanTrainer:
                                            _capi.ptr(step), c.lr, c.beta1, c.beta2, c.eps, _capi.stream_ptr()),
                     "ndp_adam_step")
 
-    def _device_noise(self):
-        _capi.check(self.lib.ndp_uniform_noise(_capi.ptr(self.noise), self.noise.numel(), self.noise_seed,
-                                               _capi.ptr(self.noise_ctr), _capi.stream_ptr()), "ndp_uniform_noise")
-        self.noise_ctr.add_(1)
-
     # the step as a list of segments; between segments the data-parallel driver
     # all-reduces the gradient the previous segment produced
     def _segments(self, device_noise):
@@ -106,9 +103,7 @@ class GanTrainer:
 
         def seg_d(first):
             def run():
-                if first and device_noise:
-                    self._device_noise()
-                self._phase_a(first)
+                self._phase_a(first, device_noise)
             return run
 
         def d_update():
@@ -203,4 +198,5 @@ class GanTrainer:
         for (m, v, step), st in (((self.g_m, self.g_v, self.g_step), g_state), ((self.d_m, self.d_v, self.d_step), d_state)):
             m.copy_(st["m"])
             v.copy_(st["v"])
-            step.fill_(int(st["t"]))
+            step.zero_()
+            step[0] = int(st["t"])

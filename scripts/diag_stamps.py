@@ -1,0 +1,76 @@
+"""Diagnostic (GPU box): in-kernel phase stamps of k_g_fwd / k_d from a -DNDP_STAMPS build
+of the library (cdna_hip_programming.md section 7, In-kernel stamps).  Prints, per phase, the
+median over workgroups of the elapsed wall time (100 MHz clock) and shader cycles."""
+import ctypes, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from ndivplanning_amd import _build, _capi
+
+lib_path = os.path.join(_build.LIB_DIR, "libndp_hip_stamps.so")
+extra = os.environ.get("NDP_CXXFLAGS", "").split()
+cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-DNDP_STAMPS"] + extra + [
+       "-Wno-unused-value", "-Wno-pass-failed", os.path.join(_build.CSRC, "ndp_kernels.hip"), "-o", lib_path]
+subprocess.check_call(cmd)
+_build.LIB_PATH = lib_path
+lib = _capi.load()
+raw = ctypes.CDLL(lib_path)
+
+from ndivplanning_amd.models.gan import Decoder, Discriminator
+from ndivplanning_amd.trainer import GanTrainer
+from oracle import gan_oracle as O
+dev = "cuda:0"
+batch, k = int(os.environ.get("B", 64)), int(os.environ.get("K", 6))
+g, d = O.init_params(0, 2)
+dec, dis = Decoder(2), Discriminator(); dec.load_state_dict(g); dis.load_state_dict(d)
+dec, dis = dec.to(dev), dis.to(dev)
+codes, actions, noise = O.synthetic_batch(0, batch, k, steps=1)
+tr = GanTrainer(dec, dis, flat=codes.shape[0], num_sample=k, use_graph=False)
+tr.codes.copy_(codes); tr.actions.copy_(actions); tr.noise.copy_(noise[0])
+for _ in range(20):
+    tr.step()
+torch.cuda.synchronize()
+stamps = torch.zeros(4096 * 32, dtype=torch.int64, device=dev)
+assert raw.ndp_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr())) == 0
+
+def report(name, fn, nphase, nwg):
+    for _ in range(int(os.environ.get("WARM", "0"))):
+        fn()
+    stamps.zero_(); torch.cuda.synchronize()
+    fn(); torch.cuda.synchronize()
+    s = stamps.cpu().numpy().reshape(-1, 16, 2)[:nwg]
+    clk, wall = s[:, :, 0].astype(np.float64), s[:, :, 1].astype(np.float64)
+    t0 = wall[:, 0].min()
+    print("%s: %d workgroups; first start -> last end %.2f us; start skew %.2f us" % (
+        name, nwg, (wall[:, nphase].max() - t0) / 100.0, (wall[:, 0].max() - t0) / 100.0))
+    for i in range(nphase):
+        dw = (wall[:, i + 1] - wall[:, i]) / 100.0
+        dc = clk[:, i + 1] - clk[:, i]
+        print("   phase %2d: median %.2f us (max %.2f)  %8.0f shader cycles  => %.2f GHz" % (
+            i, np.median(dw), dw.max(), np.median(dc), np.median(dc) / max(np.median(dw), 1e-9) / 1e3))
+
+m = codes.shape[0] * k
+mpad = (m + 31) // 32 * 32
+rt = 2 if m > 16384 else 1
+which = os.environ.get("WHICH", "g")
+if which == "w":
+    # D weight gradient: 19 jobs x chunks; run the module backward (1 pass over m rows)
+    a = torch.repeat_interleave(actions, k, dim=0).to(dev)
+    c = torch.repeat_interleave(codes, k, dim=0).to(dev)
+    def fb():
+        dis.zero_grad()
+        dis(a, c).sum().backward()
+    nch = min((512 + 18) // 19, mpad // 64, 64)
+    report("k_wgrad[D, 1 pass] [0 setup,1 main loop,2 lds write,3 reduce+store]", fb, 4, 19 * nch)
+elif which == "g":
+    # phase A launches k_g_fwd first; the k_d launch that follows overwrites the stamp buffer,
+    # so call the forward alone through the module API
+    z = torch.cat([torch.repeat_interleave(codes, k, dim=0), noise[0].reshape(m, -1)], dim=1).to(dev)
+    report("k_g_fwd  [0 load,1 fc1,2 fc2,3 fc3,4 fc4,5 fc5,6 store]", lambda: dec(z), 7, mpad // (16 * rt))
+else:
+    a = torch.repeat_interleave(actions, k, dim=0).to(dev).requires_grad_(True)
+    c = torch.repeat_interleave(codes, k, dim=0).to(dev)
+    def fb():
+        dis(a, c).sum().backward(inputs=[a])
+    report("k_d fwd+bwd [0 load,1 fc1,2 fc2,3 fc3,4 fc4,5 loss,6 store,7 dg4,8 dg3,9 dg2,10 store]",
+           fb, 11, mpad // (16 * rt))
