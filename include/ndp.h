@@ -199,6 +199,17 @@ int ndp_step_g_grads(const ndp_step_config *cfg, const ndp_step_buffers *buf,
                      const float *codes, const float *actions, const float *noise,
                      void *stream);
 
+/* The step kernels read the layers' weights from lane-ordered ("packed") copies kept in the
+ * workspace; the fused Adam updates refresh them.  Call ndp_step_pack_params once before
+ * the first step and again whenever g_params / d_params were written by anything else
+ * (checkpoint load, a host-side optimizer, ...). */
+int ndp_step_pack_params(const ndp_step_config *cfg, const ndp_step_buffers *buf, void *stream);
+
+/* Non-fused (data-parallel) update: Adam for network `which` (0 = D, 1 = G) from
+ * buf->d_grad / buf->g_grad (after the all-reduce), refreshing the packed copies. */
+int ndp_step_apply_adam(const ndp_step_config *cfg, const ndp_step_buffers *buf, int which,
+                        void *stream);
+
 /* The same device noise stream as a stand-alone call: out[i] = U[0,1) from
  * Philox-4x32-10 keyed by seed, counter (i/4, *offset_dev), word i%4. */
 int ndp_uniform_noise(float *out, int64_t n, uint64_t seed, const int32_t *offset_dev,

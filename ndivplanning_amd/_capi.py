@@ -68,6 +68,8 @@ SIGNATURES = {
                                  c_int, c_void_p]),
     "ndp_step_g_grads": (c_int, [POINTER(StepConfig), POINTER(StepBuffers), c_void_p, c_void_p, c_void_p,
                                  c_void_p]),
+    "ndp_step_pack_params": (c_int, [POINTER(StepConfig), POINTER(StepBuffers), c_void_p]),
+    "ndp_step_apply_adam": (c_int, [POINTER(StepConfig), POINTER(StepBuffers), c_int, c_void_p]),
     "ndp_uniform_noise": (c_int, [c_void_p, c_int64, c_uint64, c_void_p, c_void_p]),
     "ndp_timing_enable": (c_int, [c_int]),
     "ndp_timing_collect": (c_int, [ctypes.c_char_p, c_int, POINTER(c_float), POINTER(c_int32), c_int]),

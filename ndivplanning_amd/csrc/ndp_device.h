@@ -22,10 +22,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#ifndef NDP_ROTATE_K
-#define NDP_ROTATE_K 1
-#endif
-
 namespace ndp {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -71,6 +67,23 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 #endif
 }
 
+// Position of weight element (row j, main column k) of a layer with IN main inputs and OUT
+// outputs in the forward-packed copy: [wave][tile n][k-step t][lane = 16q + c][e].
+__device__ __forceinline__ int fwd_pack_offset(int j, int k, int in, int out) {
+  const int per_wave = out >> 2, nt = out >> 6, nit = in >> 4;
+  const int wave = j / per_wave, n = (j % per_wave) >> 4, c = j & 15;
+  const int t = k >> 4, q = (k & 15) >> 2, e = k & 3;
+  return (((wave * nt + n) * nit + t) * 64 + 16 * q + c) * 4 + e;
+}
+// ... and in the data-gradient-packed copy (dX = dY . W: reduce over row j, output column k;
+// in = columns of W, out = rows): [wave][step t][lane = 16q + c][s][v], V = in/64.
+__device__ __forceinline__ int dgrad_pack_offset(int j, int k, int in, int out) {
+  const int v_ = in >> 6, nit = out >> 4;
+  const int wave = k / (16 * v_), c = (k % (16 * v_)) / v_, v = k % v_;
+  const int t = j >> 4, q = (j & 15) >> 2, s = j & 3;
+  return (((wave * nit + t) * 64 + 16 * q + c) * 4 + s) * v_ + v;
+}
+
 template <int WALIGN>
 __device__ __forceinline__ f32x4 ldg4(const float* p) {
 #ifdef NDP_EXP_NOLOAD     // diagnostic ablation: no weight traffic
@@ -94,9 +107,14 @@ __device__ __forceinline__ f32x4 ldg4(const float* p) {
 //   Lane (q,c) loads 4 consecutive reduction indices k = 16t + 4q .. +3 of its weight
 //   row and of its activation row; MFMA step s pairs element s of both, so the four
 //   lane groups cover k = 16t + {s, 4+s, 8+s, 12+s}: a permutation of the k order.
-//   WALIGN: 4 if (Wm + j*ldw) is 16-byte aligned for every j, else 2 (8-byte).
+//   WALIGN: 4 if (Wm + j*ldw) is 16-byte aligned for every j, else 2 (8-byte), else 1.
+//   PACKED: Wm is the lane-ordered copy of the main weights (see fwd_pack_offset): the wave's
+//   fragment for column tile n, k-step t is ONE contiguous 1 KiB block, lane l at +16 l bytes.
+//   With the native [out][in] layout every quad of lanes touches 4 different cache lines
+//   (lane = weight row) and the per-CU L1 tag rate, not L2 or the MFMA pipe, sets the pace:
+//   measured 12 B/clk/CU native vs ~20 B/clk/CU packed on the 131 KB layers.
 // Caller synchronises before (X ready) and after (Y ready).
-template <int RT, int IN, int OUT, int ACT, int WALIGN>
+template <int RT, int IN, int OUT, int ACT, int WALIGN, bool PACKED = false>
 __device__ __forceinline__ void layer_fwd(const float* X, int ldx,
                                           const float* __restrict__ Wm, int ldw,
                                           const float* __restrict__ bias,
@@ -141,20 +159,15 @@ __device__ __forceinline__ void layer_fwd(const float* X, int ldx,
   constexpr int NIT = IN / 16;
   constexpr int PF0 = 96 / (4 * NT);
   constexpr int PF = PF0 < NIT ? PF0 : NIT;
-  // every workgroup walks the reduction in a different rotation, so that the workgroups of an
-  // XCD (which all read the same weights) do not hit the same L2 lines at the same moment
-  const int rot = NDP_ROTATE_K ? (int)((blockIdx.x + blockIdx.y * 5) % NIT) : 0;
-  auto koff = [&](int t) { return 16 * ((t + rot) % NIT); };
   f32x4 ring[PF][NT];
-#ifdef NDP_EXP_CONTIG   // diagnostic: same bytes, lane-contiguous 1 KiB per wave-load (wrong results)
-  auto waddr = [&](int n, int t) { return Wm + ((size_t)((wave * NT + n) * NIT + t) * 64 + lane) * 4; };
-#else
-  auto waddr = [&](int n, int t) { return wp + (size_t)(n * 16) * ldw + koff(t); };
-#endif
+  auto wfrag = [&](int n, int t) -> f32x4 {
+    if (PACKED) return ldg4<4>(Wm + ((size_t)((wave * NT + n) * NIT + t) * 64 + lane) * 4);
+    return ldg4<WALIGN>(wp + (size_t)(n * 16) * ldw + 16 * t);
+  };
 #pragma unroll
   for (int p = 0; p < PF; ++p)
 #pragma unroll
-    for (int n = 0; n < NT; ++n) ring[p][n] = ldg4<WALIGN>(waddr(n, p));
+    for (int n = 0; n < NT; ++n) ring[p][n] = wfrag(n, p);
   pin_vmem();
 
 #pragma unroll
@@ -164,11 +177,11 @@ __device__ __forceinline__ void layer_fwd(const float* X, int ldx,
     for (int n = 0; n < NT; ++n) bv[n] = ring[t % PF][n];
     if (t + PF < NIT) {
 #pragma unroll
-      for (int n = 0; n < NT; ++n) ring[t % PF][n] = ldg4<WALIGN>(waddr(n, t + PF));
+      for (int n = 0; n < NT; ++n) ring[t % PF][n] = wfrag(n, t + PF);
       pin_vmem();
     }
 #pragma unroll
-    for (int r = 0; r < RT; ++r) av[r] = *reinterpret_cast<const f32x4*>(xp + r * 16 * ldx + koff(t));
+    for (int r = 0; r < RT; ++r) av[r] = *reinterpret_cast<const f32x4*>(xp + r * 16 * ldx + 16 * t);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -209,7 +222,9 @@ __device__ __forceinline__ void layer_fwd(const float* X, int ldx,
 //   holds columns V*c .. V*c+V-1 of that group (one V-wide vector load per weight row),
 //   i.e. MFMA column tile v consists of columns {V*c + v}.  Reduction index j = 16t+4q+s
 //   pairs element s of the lane's dY vector with weight row j.
-template <int RT, int IN, int OUT, int ACT>
+//   PACKED: W is the dgrad_pack_offset copy: lane l of wave w reads its 4V floats of step t
+//   at ((w*NIT + t)*64 + l)*4V.
+template <int RT, int IN, int OUT, int ACT, bool PACKED = false>
 __device__ __forceinline__ void layer_dgrad(const float* dY, int ldd,
                                             const float* __restrict__ W, int ldw,
                                             float* H, int ldh) {
@@ -233,6 +248,16 @@ __device__ __forceinline__ void layer_dgrad(const float* dY, int ldd,
   constexpr int PF = PF0 < NIT ? PF0 : NIT;
   float ring[PF][4][V];
   auto load_step = [&](int t, float (&dst)[4][V]) {
+    if (PACKED) {
+      const float* p = W + ((size_t)(wave * NIT + t) * 64 + lane) * (4 * V);
+#pragma unroll
+      for (int h = 0; h < V; ++h) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(p + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[(4 * h + e) / V][(4 * h + e) % V] = x[e];
+      }
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const float* p = wp + (size_t)(16 * t + s) * ldw;

@@ -50,10 +50,50 @@ constexpr int TAILLD = 16;   // LDS row stride of the narrow "tail" inputs (nois
 struct GNet {
   const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4, *w5, *b5;
   int ld1, nz;
+  // lane-ordered copies (PACKED kernels): forward fc1(main 256 cols)..fc4, data-gradient fc2..fc4
+  const float *pf1, *pf2, *pf3, *pf4, *pg2, *pg3, *pg4;
 };
 struct DNet {
   const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;
+  const float *pf1, *pf2, *pf3, *pg2, *pg3;   // forward fc1(main)..fc3, data-gradient fc2, fc3
 };
+
+// Where a network's packed copies live and how canonical parameter indices map into them.
+struct PackLayer {
+  int w_off;      // canonical offset of the weight [out][ld]
+  int ld, out;    // row stride (= in features) and rows
+  int main0;      // first "main" column (0; 4 for D.fc1 whose columns 0..3 are the action tail)
+  int main_in;    // number of main columns (256 for the fc1 layers, else ld)
+  int fwd_off;    // offset of the forward-packed copy in the packed buffer, or -1
+  int dg_off;     // offset of the data-gradient-packed copy, or -1
+};
+struct PackSpec {
+  PackLayer L[4];
+  int nl;
+  float* packed;  // null: no packed copy is maintained
+};
+
+__device__ __forceinline__ void pack_store(const PackSpec& ps, int p, float v) {
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    if (l >= ps.nl) break;
+    const PackLayer& L = ps.L[l];
+    const int rel = p - L.w_off;
+    if (rel < 0 || rel >= L.out * L.ld) continue;
+    const int j = rel / L.ld, k = rel % L.ld;
+    const int km = k - L.main0;
+    if (L.fwd_off >= 0 && km >= 0 && km < L.main_in)
+      ps.packed[L.fwd_off + fwd_pack_offset(j, km, L.main_in, L.out)] = v;
+    if (L.dg_off >= 0) ps.packed[L.dg_off + dgrad_pack_offset(j, k, L.ld, L.out)] = v;
+    return;
+  }
+}
+
+struct PackArgs { const float* params; int n; PackSpec ps; };
+__global__ __launch_bounds__(kThreads) void k_pack(PackArgs a) {
+  const int p = blockIdx.x * kThreads + threadIdx.x;
+  if (p < a.n) pack_store(a.ps, p, a.params[p]);
+}
 
 // ================================================================ uniform noise (Philox-4x32-10)
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
@@ -98,7 +138,7 @@ struct GFwdArgs {
 template <int RT>
 constexpr int g_fwd_lds_floats() { return 16 * RT * (260 + TAILLD + 132 + 68 + 132 + 260 + 4); }
 
-template <int RT, int W1ALIGN>
+template <int RT, int W1ALIGN, bool PK>
 __global__ __launch_bounds__(kThreads) void k_g_fwd(GFwdArgs a) {
   constexpr int R = 16 * RT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -131,16 +171,16 @@ __global__ __launch_bounds__(kThreads) void k_g_fwd(GFwdArgs a) {
   }
   __syncthreads();
   NDP_STAMP(1);
-  layer_fwd<RT, 256, 128, ACT_RELU, W1ALIGN>(Xc, 260, n.w1, n.ld1, n.b1, H1, 132, Xt, TAILLD, n.nz, n.w1 + CODE);
+  layer_fwd<RT, 256, 128, ACT_RELU, W1ALIGN, PK>(Xc, 260, PK ? n.pf1 : n.w1, n.ld1, n.b1, H1, 132, Xt, TAILLD, n.nz, n.w1 + CODE);
   __syncthreads();
   NDP_STAMP(2);
-  layer_fwd<RT, 128, 64, ACT_RELU, 4>(H1, 132, n.w2, 128, n.b2, H2, 68, nullptr, 0, 0, nullptr);
+  layer_fwd<RT, 128, 64, ACT_RELU, 4, PK>(H1, 132, PK ? n.pf2 : n.w2, 128, n.b2, H2, 68, nullptr, 0, 0, nullptr);
   __syncthreads();
   NDP_STAMP(3);
-  layer_fwd<RT, 64, 128, ACT_RELU, 4>(H2, 68, n.w3, 64, n.b3, H3, 132, nullptr, 0, 0, nullptr);
+  layer_fwd<RT, 64, 128, ACT_RELU, 4, PK>(H2, 68, PK ? n.pf3 : n.w3, 64, n.b3, H3, 132, nullptr, 0, 0, nullptr);
   __syncthreads();
   NDP_STAMP(4);
-  layer_fwd<RT, 128, 256, ACT_RELU, 4>(H3, 132, n.w4, 128, n.b4, H4, 260, nullptr, 0, 0, nullptr);
+  layer_fwd<RT, 128, 256, ACT_RELU, 4, PK>(H3, 132, PK ? n.pf4 : n.w4, 128, n.b4, H4, 260, nullptr, 0, 0, nullptr);
   __syncthreads();
   NDP_STAMP(5);
   layer_fwd_narrow<RT, 256, 4>(H4, 260, n.w5, n.b5, A, 4);
@@ -300,7 +340,7 @@ struct DArgs {
 template <int RT, int NP>
 constexpr int d_lds_floats() { return 16 * RT * NP * (260 + TAILLD + 68 + 132 + 260 + 2) + 8; }
 
-template <int RT, int NP>
+template <int RT, int NP, bool PK>
 __global__ __launch_bounds__(kThreads) void k_d(DArgs a) {
   constexpr int R = 16 * RT;        // rows per pass
   constexpr int RR = R * NP;        // LDS rows
@@ -349,13 +389,13 @@ __global__ __launch_bounds__(kThreads) void k_d(DArgs a) {
   __syncthreads();
   NDP_STAMP(1);
   // cat([action, code]) (models/gan.py:105): weight columns 0..3 = action, 4..259 = code
-  layer_fwd<RTT, 256, 64, ACT_LRELU, 4>(Xc, 260, n.w1 + ADIM, 260, n.b1, H1, 68, Xt, TAILLD, ADIM, n.w1);
+  layer_fwd<RTT, 256, 64, ACT_LRELU, 4, PK>(Xc, 260, PK ? n.pf1 : n.w1 + ADIM, 260, n.b1, H1, 68, Xt, TAILLD, ADIM, n.w1);
   __syncthreads();
   NDP_STAMP(2);
-  layer_fwd<RTT, 64, 128, ACT_LRELU, 4>(H1, 68, n.w2, 64, n.b2, H2, 132, nullptr, 0, 0, nullptr);
+  layer_fwd<RTT, 64, 128, ACT_LRELU, 4, PK>(H1, 68, PK ? n.pf2 : n.w2, 64, n.b2, H2, 132, nullptr, 0, 0, nullptr);
   __syncthreads();
   NDP_STAMP(3);
-  layer_fwd<RTT, 128, 256, ACT_LRELU, 4>(H2, 132, n.w3, 128, n.b3, H3, 260, nullptr, 0, 0, nullptr);
+  layer_fwd<RTT, 128, 256, ACT_LRELU, 4, PK>(H2, 132, PK ? n.pf3 : n.w3, 128, n.b3, H3, 260, nullptr, 0, 0, nullptr);
   __syncthreads();
   NDP_STAMP(4);
   layer_fwd_narrow<RTT, 256, 1>(H3, 260, n.w4, n.b4, L, 1);
@@ -408,10 +448,10 @@ __global__ __launch_bounds__(kThreads) void k_d(DArgs a) {
   layer_dgrad_narrow<RTT, 256, 1, ACT_LRELU>(DL, 1, n.w4, H3, 260);          // H3 := dY3
   __syncthreads();
   NDP_STAMP(8);
-  layer_dgrad<RTT, 128, 256, ACT_LRELU>(H3, 260, n.w3, 128, H2, 132);         // H2 := dY2
+  layer_dgrad<RTT, 128, 256, ACT_LRELU, PK>(H3, 260, PK ? n.pg3 : n.w3, 128, H2, 132);   // H2 := dY2
   __syncthreads();
   NDP_STAMP(9);
-  layer_dgrad<RTT, 64, 128, ACT_LRELU>(H2, 132, n.w2, 64, H1, 68);            // H1 := dY1
+  layer_dgrad<RTT, 64, 128, ACT_LRELU, PK>(H2, 132, PK ? n.pg2 : n.w2, 64, H1, 68);      // H1 := dY1
   __syncthreads();
   NDP_STAMP(10);
   if (a.dy1 != nullptr) {
@@ -449,7 +489,7 @@ struct GBwdArgs {
 template <int RT>
 constexpr int g_bwd_lds_floats() { return 16 * RT * (132 + 68 + 132 + 260 + 4); }
 
-template <int RT>
+template <int RT, bool PK>
 __global__ __launch_bounds__(kThreads) void k_g_bwd(GBwdArgs a) {
   constexpr int R = 16 * RT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -478,11 +518,11 @@ __global__ __launch_bounds__(kThreads) void k_g_bwd(GBwdArgs a) {
   __syncthreads();
   layer_dgrad_narrow<RT, 256, 4, ACT_RELU>(DA, 4, n.w5, H4, 260);     // H4 := dY4
   __syncthreads();
-  layer_dgrad<RT, 128, 256, ACT_RELU>(H4, 260, n.w4, 128, H3, 132);   // H3 := dY3
+  layer_dgrad<RT, 128, 256, ACT_RELU, PK>(H4, 260, PK ? n.pg4 : n.w4, 128, H3, 132);   // H3 := dY3
   __syncthreads();
-  layer_dgrad<RT, 64, 128, ACT_RELU>(H3, 132, n.w3, 64, H2, 68);      // H2 := dY2
+  layer_dgrad<RT, 64, 128, ACT_RELU, PK>(H3, 132, PK ? n.pg3 : n.w3, 64, H2, 68);      // H2 := dY2
   __syncthreads();
-  layer_dgrad<RT, 128, 64, ACT_RELU>(H2, 68, n.w2, 128, H1, 132);     // H1 := dY1
+  layer_dgrad<RT, 128, 64, ACT_RELU, PK>(H2, 68, PK ? n.pg2 : n.w2, 128, H1, 132);     // H1 := dY1
   __syncthreads();
   store_tile<RT, 128>(a.dy1 + row0 * 128, 128, H1, 132);
   store_tile<RT, 64>(a.dy2 + row0 * 64, 64, H2, 68);
@@ -708,6 +748,7 @@ struct ReduceArgs {
   float lr, beta1, beta2, eps;
   LossTerm loss[3]; int nloss;
   float* losses; float* loss_sums;
+  PackSpec pack;                       // lane-ordered copies to refresh with the new parameters
 };
 
 __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v,
@@ -743,6 +784,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce_adam(ReduceArgs a) {
       a.params[p] = pv;
       a.exp_avg[p] = m;
       a.exp_avg_sq[p] = v;
+      if (a.pack.packed != nullptr) pack_store(a.pack, (int)p, pv);
     }
   }
   if (blockIdx.x == 0) {
@@ -765,6 +807,7 @@ __global__ void k_adam_advance(int32_t* state, float lr, float b1, float b2) { a
 struct AdamArgs {
   float *params, *exp_avg, *exp_avg_sq; const float* grad; int64_t n;
   const int32_t* step; float lr, beta1, beta2, eps;
+  PackSpec pack;
 };
 __global__ __launch_bounds__(kThreads) void k_adam(AdamArgs a) {
   const float step_size = reinterpret_cast<const float*>(a.step)[1];
@@ -776,6 +819,7 @@ __global__ __launch_bounds__(kThreads) void k_adam(AdamArgs a) {
     a.params[p] = pv;
     a.exp_avg[p] = m;
     a.exp_avg_sq[p] = v;
+    if (a.pack.packed != nullptr) pack_store(a.pack, (int)p, pv);
   }
 }
 

@@ -68,6 +68,15 @@ class GanTrainer:
         self._bind()
 
     # -- plumbing ---------------------------------------------------------------
+    def _versions(self):
+        return (self.g_flat._version, self.d_flat._version)
+
+    def _repack(self):
+        """Rebuild the lane-ordered weight copies the step kernels read (include/ndp.h)."""
+        _capi.check(self.lib.ndp_step_pack_params(ctypes.byref(self.cfg), ctypes.byref(self.buf), _capi.stream_ptr()),
+                    "ndp_step_pack_params")
+        self._seen_versions = self._versions()
+
     def _bind(self):
         self.g_flat = self.decoder.flat_parameters()
         self.d_flat = self.discriminator.flat_parameters()
@@ -77,6 +86,7 @@ class GanTrainer:
             d_params=p(self.d_flat), d_grad=p(self.d_grad), d_exp_avg=p(self.d_m), d_exp_avg_sq=p(self.d_v),
             g_step=p(self.g_step), d_step=p(self.d_step), losses=p(self.losses_dev), loss_sums=p(self.loss_sums),
             action_hat=p(self.action_hat), workspace=p(self.workspace))
+        self._repack()
 
     def _phase_a(self, first, device_noise=False):
         # device noise: the G forward kernel draws U[0,1) itself and fills self.noise
@@ -90,12 +100,6 @@ class GanTrainer:
                                               _capi.ptr(self.actions), _capi.ptr(self.noise), _capi.stream_ptr()),
                     "ndp_step_g_grads")
 
-    def _adam(self, flat, grad, m, v, step):
-        c = self.cfg
-        _capi.check(self.lib.ndp_adam_step(_capi.ptr(flat), _capi.ptr(grad), _capi.ptr(m), _capi.ptr(v), flat.numel(),
-                                           _capi.ptr(step), c.lr, c.beta1, c.beta2, c.eps, _capi.stream_ptr()),
-                    "ndp_adam_step")
-
     # the step as a list of segments; between segments the data-parallel driver
     # all-reduces the gradient the previous segment produced
     def _segments(self, device_noise):
@@ -107,10 +111,12 @@ class GanTrainer:
             return run
 
         def d_update():
-            self._adam(self.d_flat, self.d_grad, self.d_m, self.d_v, self.d_step)
+            _capi.check(self.lib.ndp_step_apply_adam(ctypes.byref(self.cfg), ctypes.byref(self.buf), 0,
+                                                     _capi.stream_ptr()), "ndp_step_apply_adam")
 
         def g_update():
-            self._adam(self.g_flat, self.g_grad, self.g_m, self.g_v, self.g_step)
+            _capi.check(self.lib.ndp_step_apply_adam(ctypes.byref(self.cfg), ctypes.byref(self.buf), 1,
+                                                     _capi.stream_ptr()), "ndp_step_apply_adam")
 
         fused = self.reduce_fn is None
         for it in range(self.discrim_steps):
@@ -160,6 +166,10 @@ class GanTrainer:
                 self.d_flat.data_ptr() != self.discriminator.flat_parameters().data_ptr():
             self._bind()
             self._graphs = None
+        elif self._versions() != self._seen_versions:
+            # somebody wrote the parameters through torch (load_state_dict, copy_, an optimizer):
+            # the kernels' packed copies are stale
+            self._repack()
         if codes is not None:
             self.codes.copy_(codes.reshape(self.flat, CODE_DIM), non_blocking=True)
         if actions is not None:

@@ -434,11 +434,21 @@ def test_data_parallel_two_shards_equal_global_batch():
                 summed.append(total.clone())
                 for r in range(2):
                     segs[r][i][1].copy_(total)
-        for name, mine, ref in (("D", summed[0], whole_grads[0]), ("G", summed[1], whole_grads[1])):
+            if i == 1:
+                # D has been updated on every replica.  Continue the G phase from the whole-batch
+                # trainer's D so that the G-gradient comparison sees summation order only (Adam
+                # turns the last-bit differences of the summed D gradient into +-lr moves).
+                for t in ranks:
+                    _params_close_floor(t.d_flat, whole.d_flat, whole_grads[0], 1e-5, 2e-4, 1, "D params step %d" % s)
+                    with torch.no_grad():
+                        t.d_flat.copy_(whole.d_flat)
+                    t._repack()
+        # summation order only; the G gradient sums NDiv terms of both signs that are ~100x
+        # larger than the result, hence the wider relative band
+        for name, mine, ref, rtol in (("D", summed[0], whole_grads[0], 2e-5), ("G", summed[1], whole_grads[1], 1e-4)):
             scale = max(1.0, ref.abs().max().item())
-            _close(mine, ref, 2e-5 * scale, "%s gradient: sum of shards vs whole batch, step %d" % (name, s))
+            _close(mine, ref, rtol * scale, "%s gradient: sum of shards vs whole batch, step %d" % (name, s))
         for t in ranks:
-            _params_close_floor(t.d_flat, whole.d_flat, whole_grads[0], 1e-5, 2e-4, 1, "D params step %d" % s)
             _params_close_floor(t.g_flat, whole.g_flat, whole_grads[1], 1e-5 * max(1.0, whole_grads[1].abs().max().item()),
                                 2e-4, 1, "G params step %d" % s)
             assert torch.equal(t.g_flat, ranks[0].g_flat) and torch.equal(t.d_flat, ranks[0].d_flat)
