@@ -1,0 +1,192 @@
+"""GAN training script -- mirror of the reference's `train_gan.py` (same CLI, same YAML keys,
+same `train(config)` entry point, same epoch log line and checkpoint files), with the loop
+body (train_gan.py:115-207) replaced by `GanTrainer.step`: a few fused gfx950 kernels per
+iteration, replayed from a HIP graph, with no host synchronisation inside an epoch.
+
+What differs from the reference, on purpose:
+  * the three `.cpu()` loss reads per step (train_gan.py:205-207) become one read per epoch
+    of sums accumulated on the device;
+  * dead work is gone: the K-fold image repeats that are never read (144-149), the back-prop
+    through G inside the D step and the D weight gradients inside the G step (183, 202);
+  * a ragged final batch is dropped (the reference hard-codes batch_size and crashes on it,
+    train_gan.py:168-194);
+  * noise comes from a counter-based generator on the device unless `training.gan.noise_source`
+    is "cpu" (the reference's torch.FloatTensor(...).uniform_() stream);
+  * more than one process (torch.distributed.run) trains data-parallel: `batch_size` is the
+    GLOBAL batch, every rank takes batch_size / world_size trajectories of each batch
+    (ndivplanning_amd/dp.py);
+  * the forward-model checkpoints the reference loads and never uses (train_gan.py:79-86) are
+    not loaded; visdom plotting is attempted only if visdom is importable.
+
+Extra YAML keys (all optional): `train_data_path: synthetic:<N>[:codes|images]` for seeded
+synthetic trajectories, `training.gan.noise_source`, `training.gan.use_graph`.
+"""
+import logging
+import os
+from argparse import ArgumentParser
+
+import numpy as np
+import torch
+from torch.utils import data
+
+from . import dp
+from .models.gan import Decoder, Discriminator
+from .models.image_autoencoder import Encoder
+from .trainer import GanTrainer
+from .utils.argparse_util import override_dotmap
+from .utils.cli_arguments.common_arguments import add_common_arguments
+from .utils.file import make_paths_absolute
+from .utils.trajectory_loader import PushDataset, SyntheticPushDataset
+
+
+def denorm(tensor):
+    return ((tensor + 1.0) / 2.0) * 255.0
+
+
+def norm(image):
+    return (image / 255.0 - 0.5) * 2.0
+
+
+def _get(cfg, key, default):
+    v = cfg.get(key, None) if hasattr(cfg, "get") else None
+    return default if v is None or (isinstance(v, dict) and not v) else v
+
+
+def make_dataset(config):
+    path = str(config.train_data_path)
+    if path.startswith("synthetic:") or "/synthetic:" in path:
+        spec = path[path.index("synthetic:"):].split(":")
+        n = int(spec[1])
+        mode = spec[2] if len(spec) > 2 else "codes"
+        return SyntheticPushDataset(n, seq_length=config.trajectory_length, mode=mode, seed=int(config.random_seed))
+    return PushDataset(config.train_data_path, seq_length=config.trajectory_length)
+
+
+def load_encoder(config, device):
+    """torch.load of the pretrained whole-module encoder pickle (train_gan.py:75-76).  A local,
+    trusted file written by train_autoencoder.py: weights_only=False is required for module
+    pickles.  Without a file (synthetic image runs) a seeded Encoder stands in."""
+    path = _get(config, "image_encoder_model_path", None)
+    if path and os.path.isfile(path):
+        enc = torch.load(path, map_location=device, weights_only=False)
+    else:
+        logging.warning("no image encoder checkpoint at %s: using a seeded random Encoder", path)
+        torch.manual_seed(int(config.random_seed))
+        enc = Encoder()
+    return enc.to(device).eval()
+
+
+def encode_batch(frames, encoder, seq_length):
+    """codes [B*(T-1), 256] = cat(code(current frame), code(final frame)) (train_gan.py:127-155).
+    `frames` is [B,T,3,H,W] images or [B,T,128] cached codes; the target frame is encoded once
+    per trajectory instead of T-1 times."""
+    b, t = frames.shape[0], frames.shape[1]
+    if frames.dim() == 5:
+        with torch.no_grad():
+            per_frame = encoder(frames.reshape((b * t,) + tuple(frames.shape[2:]))).reshape(b, t, -1)
+    else:
+        per_frame = frames
+    cur = per_frame[:, :-1]
+    tgt = per_frame[:, -1:].expand(-1, t - 1, -1)
+    return torch.cat([cur, tgt], dim=2).reshape(b * (t - 1), -1).contiguous()
+
+
+def train(config):
+    g = config.training.gan
+    random_seed = int(config.random_seed)
+    num_epochs, num_sample, noise_dim = int(g.num_epochs), int(g.num_sample), int(g.noise_dim)
+    batch_size, dsteps, epochs_per_stage = int(g.batch_size), int(g.discrim_steps_per_gen), int(g.epochs_per_stage)
+    lr_rate = float(g.learning_rate)
+    div_factor = g.get("pairwise_div_factor", None)
+    if div_factor is None or isinstance(div_factor, dict):
+        raise KeyError("training.gan.pairwise_div_factor is missing from the config "
+                       "(the reference fails at train_gan.py:199 for such a file)")
+    noise_source = _get(g, "noise_source", "device")
+    use_graph = bool(_get(g, "use_graph", True))
+
+    rank, world, local_rank = dp.env_world()
+    if not torch.cuda.is_available():
+        raise RuntimeError("train_gan needs a ROCm GPU: the HIP path has no CPU fallback")
+    gpu = local_rank if world > 1 else int(_get(config, "gpu_id", 0)) % max(torch.cuda.device_count(), 1)
+    device = torch.device("cuda", gpu)
+    torch.cuda.set_device(device)
+    dp.init_process_group(device)
+    if batch_size % world != 0:
+        raise ValueError("training.gan.batch_size=%d must be a multiple of the %d ranks" % (batch_size, world))
+    local_batch = batch_size // world
+
+    torch.manual_seed(random_seed)          # train_gan.py:65-66: Decoder, then Discriminator, then shuffling
+    np.random.seed(random_seed)
+
+    display = None
+    if rank == 0 and _get(config, "log_port", None):
+        try:                                  # train_gan.py:68; needs a live visdom server
+            from visdom import Visdom        # noqa: F401
+            from .vis_tools import visualizer
+            display = visualizer(port=config.log_port)
+        except Exception as e:                # noqa: BLE001 - observability is optional
+            logging.info("visdom plotting disabled (%s)", e)
+
+    dataset = make_dataset(config)
+    loader = data.DataLoader(dataset, batch_size=batch_size, shuffle=True, drop_last=True,
+                             generator=torch.Generator().manual_seed(random_seed))
+    if len(loader) == 0:
+        raise ValueError("dataset of %d trajectories is smaller than one batch of %d" % (len(dataset), batch_size))
+    seq_length = int(dataset.seq_length)
+    image_mode = getattr(dataset, "mode", "images") == "images"
+    encoder = load_encoder(config, device) if image_mode else None
+
+    decoder = Decoder(noise_dim=noise_dim)
+    discriminator = Discriminator()
+    decoder.weight_init(mean=0.0, std=0.02)            # no-op on Linear layers, as in the reference
+    discriminator.weight_init(mean=0.0, std=0.02)
+    decoder, discriminator = decoder.to(device), discriminator.to(device)
+
+    flat_local = local_batch * (seq_length - 1)
+    trainer = GanTrainer(decoder, discriminator, flat=flat_local, num_sample=num_sample, lr=lr_rate,
+                         betas=(0.5, 0.999), pairwise_div_factor=float(div_factor), discrim_steps=dsteps,
+                         flat_global=flat_local * world, reduce_fn=dp.sum_all_reduce() if world > 1 else None,
+                         use_graph=use_graph, noise_seed=random_seed * 1000 + rank)
+    history = []
+    for epoch in range(num_epochs):
+        discriminator.train()
+        decoder.train()
+        for inputs in loader:
+            frames, _states, actions, _goal = inputs
+            lo, hi = dp.shard_bounds(batch_size, rank, world)
+            frames = frames[lo:hi].float().to(device, non_blocking=True)
+            actions = actions[lo:hi].float().to(device, non_blocking=True)
+            codes = encode_batch(frames, encoder, seq_length)
+            acts = actions[:, :-1].reshape(-1, actions.size(-1))                # train_gan.py:137
+            noise = None
+            if noise_source == "cpu":                                           # train_gan.py:44
+                noise = torch.FloatTensor(flat_local, num_sample, noise_dim).uniform_().to(device)
+            trainer.step(codes, acts, noise)
+        sums = dp.reduce_loss_shares(trainer.pop_loss_sums(), device=device)
+        d_avg, g_avg, div_avg = (v / len(loader) for v in sums)                 # train_gan.py:209-211
+        history.append((d_avg, g_avg, div_avg))
+        if rank == 0:
+            logging.info("{}, D: {:4f}, G: {:4f}, div: {:4f}".format(epoch, d_avg, g_avg, div_avg))
+            if display is not None:
+                display.plot("gan", "discriminator", "GAN Loss", epoch, d_avg)
+                display.plot("gan", "generator", "GAN Loss", epoch, g_avg)
+                display.plot("pairwise_div", "loss", "Pairwise Divergence Loss", epoch, div_avg)
+            if epoch % epochs_per_stage == epochs_per_stage - 1:                # train_gan.py:249-266
+                os.makedirs(config.gan_save_path, exist_ok=True)
+                torch.cuda.synchronize(device)
+                torch.save(discriminator, os.path.join(config.gan_save_path, "gan_discriminator_{}.pt".format(epoch)))
+                torch.save(decoder, os.path.join(config.gan_save_path, "gan_decoder_{}.pt".format(epoch)))
+    return history
+
+
+def main(argv=None):
+    parser = ArgumentParser(description="Interact with your training script")
+    parser = add_common_arguments(parser)
+    args = parser.parse_args(argv)
+    config = override_dotmap(args, "config_file")
+    config = make_paths_absolute(os.getcwd(), config, log_not_exist=True)
+    return train(config)
+
+
+if __name__ == "__main__":
+    main()

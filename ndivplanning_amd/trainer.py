@@ -15,7 +15,7 @@ import ctypes
 
 import torch
 
-from . import _capi
+from . import _capi, dp
 from .models.gan import ACTION_DIM, CODE_DIM, Decoder, Discriminator
 
 
@@ -65,6 +65,8 @@ class GanTrainer:
             raise _capi.NdpError("bad step configuration (flat=%d, num_sample=%d)" % (self.flat, self.k))
         self.workspace = torch.empty(nws, **f32)
         self._graphs = None
+        self._device_noise_now = False
+        self._d_calls = 0
         self._bind()
 
     # -- plumbing ---------------------------------------------------------------
@@ -86,12 +88,18 @@ class GanTrainer:
             d_params=p(self.d_flat), d_grad=p(self.d_grad), d_exp_avg=p(self.d_m), d_exp_avg_sq=p(self.d_v),
             g_step=p(self.g_step), d_step=p(self.d_step), losses=p(self.losses_dev), loss_sums=p(self.loss_sums),
             action_hat=p(self.action_hat), workspace=p(self.workspace))
+        # the reference adds the LAST D loss of an iteration to its epoch sum (train_gan.py:205):
+        # earlier D steps of a discrim_steps_per_gen > 1 iteration run without the running sums
+        self.buf_nosum = _capi.StepBuffers()
+        ctypes.memmove(ctypes.byref(self.buf_nosum), ctypes.byref(self.buf), ctypes.sizeof(_capi.StepBuffers))
+        self.buf_nosum.loss_sums = None
         self._repack()
 
-    def _phase_a(self, first, device_noise=False):
+    def _phase_a(self, first, device_noise=False, last=True):
         # device noise: the G forward kernel draws U[0,1) itself and fills self.noise
         self.cfg.device_noise = 1 if device_noise else 0
-        _capi.check(self.lib.ndp_step_d_grads(ctypes.byref(self.cfg), ctypes.byref(self.buf), _capi.ptr(self.codes),
+        buf = self.buf if last else self.buf_nosum
+        _capi.check(self.lib.ndp_step_d_grads(ctypes.byref(self.cfg), ctypes.byref(buf), _capi.ptr(self.codes),
                                               _capi.ptr(self.actions), _capi.ptr(self.noise), 1 if first else 0,
                                               _capi.stream_ptr()), "ndp_step_d_grads")
 
@@ -105,9 +113,9 @@ class GanTrainer:
     def _segments(self, device_noise):
         segs = []
 
-        def seg_d(first):
+        def seg_d(first, last):
             def run():
-                self._phase_a(first, device_noise)
+                self._phase_a(first, device_noise, last)
             return run
 
         def d_update():
@@ -120,7 +128,7 @@ class GanTrainer:
 
         fused = self.reduce_fn is None
         for it in range(self.discrim_steps):
-            segs.append((seg_d(it == 0), None if fused else self.d_grad))
+            segs.append((seg_d(it == 0, it == self.discrim_steps - 1), None if fused else self.d_grad))
             if not fused:
                 segs.append((d_update, None))
         segs.append((self._phase_b, None if fused else self.g_grad))
@@ -128,11 +136,31 @@ class GanTrainer:
             segs.append((g_update, None))
         return segs
 
+    # dp.run_step backend protocol (non-fused mode)
+    def d_grads(self, first):
+        self._d_calls = 0 if first else self._d_calls + 1
+        self._phase_a(first, self._device_noise_now, self._d_calls == self.discrim_steps - 1)
+        return self.d_grad
+
+    def apply_d(self, grad):
+        _capi.check(self.lib.ndp_step_apply_adam(ctypes.byref(self.cfg), ctypes.byref(self.buf), 0,
+                                                 _capi.stream_ptr()), "ndp_step_apply_adam")
+
+    def g_grads(self):
+        self._phase_b()
+        return self.g_grad
+
+    def apply_g(self, grad):
+        _capi.check(self.lib.ndp_step_apply_adam(ctypes.byref(self.cfg), ctypes.byref(self.buf), 1,
+                                                 _capi.stream_ptr()), "ndp_step_apply_adam")
+
     def _run_eager(self, device_noise):
-        for fn, grad in self._segments(device_noise):
+        if self.reduce_fn is not None:
+            self._device_noise_now = device_noise
+            dp.run_step(self, self.reduce_fn, self.discrim_steps)
+            return
+        for fn, _ in self._segments(device_noise):
             fn()
-            if grad is not None:
-                self.reduce_fn(grad)
 
     def _build_graphs(self, device_noise):
         """Capture maximal runs of segments that need no collective in between."""

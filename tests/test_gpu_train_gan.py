@@ -1,0 +1,127 @@
+"""GPU tests of the training script mirror (ndivplanning_amd/train_gan.py): an epoch against
+the oracle's replay of the same epoch, checkpoints, image mode, and two data-parallel ranks."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import gan_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _config(tmp_path, n_traj, mode, batch, k=6, epochs=1, dsteps=1, noise_source="cpu", stage=1):
+    from ndivplanning_amd.utils.file import AttrDict
+    return AttrDict({
+        "random_seed": 0, "train_data_path": "synthetic:%d:%s" % (n_traj, mode), "gpu_id": 0,
+        "gan_save_path": str(tmp_path / "gan"), "trajectory_length": 8,
+        "image_encoder_model_path": str(tmp_path / "no_encoder.pt"),
+        "training": {"gan": {"num_epochs": epochs, "num_sample": k, "noise_dim": 2, "learning_rate": 2e-4,
+                             "report_feq": 10, "batch_size": batch, "discrim_steps_per_gen": dsteps,
+                             "epochs_per_stage": stage, "pairwise_div_factor": 0.1,
+                             "noise_source": noise_source, "use_graph": True}}})
+
+
+def _oracle_epoch(cfg):
+    """Replay of train() on the CPU with the oracle: same RNG order (seed -> Decoder ->
+    Discriminator -> per-step uniform_ noise), same seeded loader."""
+    from ndivplanning_amd.train_gan import encode_batch, make_dataset
+    g_cfg = cfg.training.gan
+    torch.manual_seed(cfg.random_seed)
+    g, d = O.init_params(cfg.random_seed, g_cfg.noise_dim)        # seeds and constructs in the reference order
+    ds = make_dataset(cfg)
+    loader = torch.utils.data.DataLoader(ds, batch_size=g_cfg.batch_size, shuffle=True, drop_last=True,
+                                         generator=torch.Generator().manual_seed(cfg.random_seed))
+    sm = O.StepMath(g, d, lr=g_cfg.learning_rate, pairwise_div_factor=g_cfg.pairwise_div_factor)
+    sums = [0.0, 0.0, 0.0]
+    for frames, _s, actions, _g in loader:
+        codes = encode_batch(frames.float(), None, ds.seq_length)
+        acts = actions.float()[:, :-1].reshape(-1, 4)
+        noise = torch.FloatTensor(codes.shape[0], g_cfg.num_sample, g_cfg.noise_dim).uniform_()
+        out = sm.step(codes, acts, noise, discrim_steps=g_cfg.discrim_steps_per_gen)
+        for i, key in enumerate(("d_loss", "g_loss", "pair_div")):
+            sums[i] += out[key].item()
+    return [v / len(loader) for v in sums], sm
+
+
+@pytest.mark.parametrize("dsteps", [1, 2])
+def test_epoch_matches_oracle_replay(tmp_path, dsteps):
+    from ndivplanning_amd.train_gan import train
+    cfg = _config(tmp_path, 24, "codes", 8, dsteps=dsteps)
+    hist = train(cfg)
+    want, _ = _oracle_epoch(_config(tmp_path, 24, "codes", 8, dsteps=dsteps))
+    d_avg, g_avg, div_avg = hist[0]
+    assert abs(d_avg - want[0]) <= 1e-4 and abs(g_avg - want[1]) <= 1e-4
+    assert abs(div_avg - want[2]) <= 5e-2 * abs(want[2])           # free-running over 3 steps, FLAT = 56
+
+
+def test_checkpoints_are_reference_style_whole_modules(tmp_path):
+    import models.gan as shim
+    from ndivplanning_amd.train_gan import train
+    cfg = _config(tmp_path, 16, "codes", 8, epochs=2, stage=2, noise_source="device")
+    train(cfg)
+    files = sorted(os.listdir(cfg.gan_save_path))
+    assert files == ["gan_decoder_1.pt", "gan_discriminator_1.pt"]     # epoch % stage == stage - 1
+    dec = torch.load(os.path.join(cfg.gan_save_path, "gan_decoder_1.pt"), weights_only=False)
+    dis = torch.load(os.path.join(cfg.gan_save_path, "gan_discriminator_1.pt"), weights_only=False)
+    assert isinstance(dec, shim.Decoder) and isinstance(dis, shim.Discriminator)
+    z = torch.randn(12, 258, device="cuda:0")
+    a = dec(z)                                                          # runs on the HIP path after unpickling
+    ref = O.g_forward({k: v.cpu() for k, v in dec.state_dict().items()}, z.cpu())
+    assert (a.cpu() - ref).abs().max() <= 1e-4
+    assert dis(a.detach(), z[:, :256].contiguous()).shape == (12, 1)
+
+
+def test_image_mode_runs(tmp_path):
+    from ndivplanning_amd.train_gan import train
+    cfg = _config(tmp_path, 4, "images", 2, k=3, noise_source="device")
+    hist = train(cfg)
+    assert all(torch.isfinite(torch.tensor(h)).all() for h in hist)
+    assert 1.0 < hist[0][0] < 2.0 and 0.3 < hist[0][1] < 1.2            # ~2 ln 2 and ~ln 2 at initialisation
+
+
+def _rank_main(rank, world, port, cfg_dict, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", NDP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from ndivplanning_amd import train_gan
+    from ndivplanning_amd.utils.file import AttrDict
+    cfg = AttrDict(cfg_dict)
+    captured = {}
+    real_trainer = train_gan.GanTrainer
+
+    def spy(*a, **kw):
+        captured["t"] = real_trainer(*a, **kw)
+        return captured["t"]
+    train_gan.GanTrainer = spy
+    hist = train_gan.train(cfg)
+    t = captured["t"]
+    torch.save({"g": t.g_flat.cpu(), "d": t.d_flat.cpu(), "hist": hist}, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_single_process(tmp_path):
+    """2 processes (gloo, both on cuda:0) each training half of every global batch of 8 vs one
+    process training the whole batch: same epoch losses, same parameters up to Adam's noise."""
+    from ndivplanning_amd import train_gan
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cfg = _config(tmp_path, 16, "codes", 8, noise_source="device")
+    cfg.training.gan.use_graph = False
+    # device noise is keyed by rank, so the comparison fixes the noise through the CPU stream:
+    # not available across processes either -> compare the invariants instead
+    mp.spawn(_rank_main, args=(2, port, cfg.toDict(), str(tmp_path)), nprocs=2, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(2)]
+    assert torch.equal(res[0]["g"], res[1]["g"]) and torch.equal(res[0]["d"], res[1]["d"])   # replicas in lockstep
+    assert res[0]["hist"] == res[1]["hist"]
+    d_avg, g_avg, div_avg = res[0]["hist"][0]
+    assert 1.2 < d_avg < 1.5 and 0.6 < g_avg < 0.8 and div_avg > 0.0
+    g0, _ = O.init_params(0, 2)
+    moved = (res[0]["g"] - torch.cat([v.reshape(-1) for v in g0.values()])).abs()
+    assert 0 < moved.max() <= 2 * 2.5 * 2e-4                                              # two Adam steps happened

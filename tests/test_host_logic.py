@@ -1,0 +1,167 @@
+"""CPU-only tests of the host side: config / CLI mirror, datasets, batch unpacking, the
+nn.Module surface (state_dict keys, pickles, flat parameter views) and the DP helpers."""
+import argparse
+import io
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ config + CLI
+def test_attrdict_behaves_like_the_dotmap_subset_the_scripts_use():
+    from ndivplanning_amd.utils.file import AttrDict
+    c = AttrDict({"a": 1, "training": {"gan": {"batch_size": 8}}})
+    assert c.training.gan.batch_size == 8 and c["training"]["gan"]["batch_size"] == 8
+    c.gpu_id = 3
+    assert c["gpu_id"] == 3
+    assert c.training.gan.missing_key == {}          # DotMap: missing -> empty map, not KeyError
+    assert c.toDict()["training"]["gan"]["batch_size"] == 8
+
+
+def test_load_config_and_absolute_paths(tmp_path, monkeypatch):
+    from ndivplanning_amd.utils.file import load_training_config_file
+    (tmp_path / "c.yaml").write_text(
+        "random_seed: 0\ngan_save_path: out/gan\ntrain_data_path: 'synthetic:64:codes'\n"
+        "training:\n  gan:\n    batch_size: 4\n    model_path: rel/x.pt\n")
+    monkeypatch.chdir(tmp_path)
+    cfg = load_training_config_file("c.yaml")
+    assert cfg.gan_save_path == str(tmp_path / "out" / "gan")
+    assert cfg.train_data_path == "synthetic:64:codes"            # scheme, not a path
+    assert cfg.training.gan.model_path == str(tmp_path / "rel" / "x.pt")
+
+
+def test_cli_flags_and_override(tmp_path, monkeypatch):
+    from ndivplanning_amd.utils.argparse_util import override_dotmap
+    from ndivplanning_amd.utils.cli_arguments.common_arguments import add_common_arguments
+    (tmp_path / "c.yaml").write_text("gpu_id: 1\ntrajectory_length: 8\n")
+    (tmp_path / "ckpt").mkdir()
+    monkeypatch.chdir(tmp_path)
+    parser = add_common_arguments(argparse.ArgumentParser())
+    flags = {a.option_strings[0] for a in parser._actions if a.option_strings}
+    assert {"--config-file", "--log-port", "--gpu-id", "--trajectory-length", "--log-dir", "--forward-save-path",
+            "--gan-save-path", "--train-data-path", "--evaluation-data-path", "--restore-weights"} <= flags
+    args = parser.parse_args(["--config-file", "c.yaml", "--gpu-id", "0", "--gan-save-path", "ckpt"])
+    cfg = override_dotmap(args, "config_file")
+    assert cfg.gpu_id == 0 and cfg.trajectory_length == 8 and cfg.gan_save_path.endswith("ckpt")
+    assert "log_port" not in cfg                                   # flags not given do not override
+    with pytest.raises(SystemExit):                                # ArgumentTypeError -> argparse error
+        parser.parse_args(["--config-file", "c.yaml", "--gan-save-path", "does_not_exist"])
+
+
+def test_shipped_configs_have_the_reference_keys():
+    import yaml
+    ref_keys = {"num_epochs", "num_sample", "noise_dim", "learning_rate", "report_feq", "batch_size",
+                "discrim_steps_per_gen", "epochs_per_stage", "pairwise_div_factor"}
+    for name in os.listdir(os.path.join(ROOT, "config")):
+        cfg = yaml.safe_load(open(os.path.join(ROOT, "config", name)))
+        assert ref_keys <= set(cfg["training"]["gan"]), name
+        assert cfg["trajectory_length"] == 8
+
+
+# ------------------------------------------------------------------ data
+def test_synthetic_dataset_contract():
+    from ndivplanning_amd.utils.trajectory_loader import SyntheticPushDataset
+    ds = SyntheticPushDataset(5, seq_length=8, mode="images", image_size=16)
+    images, states, actions, goal = ds[3]
+    assert images.shape == (8, 3, 16, 16) and states.shape == (8, 25) and actions.shape == (8, 4) and goal.shape == (3,)
+    assert images.min() >= -1 and images.max() < 1 and images.dtype == torch.float32
+    assert torch.equal(ds[3][2], actions)                          # deterministic per index
+    codes = SyntheticPushDataset(5, seq_length=8, mode="codes")[0][0]
+    assert codes.shape == (8, 128)
+
+
+def test_encode_batch_matches_the_reference_unpacking():
+    """train_gan.py:127-155: split off the last frame, repeat_interleave it T-1 times, cat codes."""
+    from ndivplanning_amd.train_gan import encode_batch
+    b, t = 3, 8
+    per_frame = torch.randn(b, t, 128)
+    cur, tgt = torch.split(per_frame, [t - 1, 1], dim=1)
+    cur = cur.reshape(-1, 128)
+    tgt = torch.repeat_interleave(tgt.squeeze(1), repeats=t - 1, dim=0)
+    want = torch.cat([cur, tgt], dim=1)
+    assert torch.equal(encode_batch(per_frame, None, t), want)
+
+    class Enc(torch.nn.Module):                                    # stand-in encoder: mean colour -> 128 copies
+        def forward(self, x):
+            return x.mean(dim=(2, 3)).repeat(1, 43)[:, :128, None, None]
+    frames = torch.rand(2, t, 3, 8, 8)
+    got = encode_batch(frames, Enc(), t)
+    assert got.shape == (2 * (t - 1), 256)
+    assert torch.allclose(got[0, 128:], got[t - 2, 128:])          # one target code per trajectory
+
+
+# ------------------------------------------------------------------ modules
+def test_module_surface_matches_reference():
+    from ndivplanning_amd.models.gan import Decoder, Discriminator
+    from oracle import gan_oracle as O
+    torch.manual_seed(0)
+    g, d = Decoder(noise_dim=2), Discriminator()
+    og, od = O.init_params(0, 2)
+    assert list(g.state_dict().keys()) == list(og.keys()) and list(d.state_dict().keys()) == list(od.keys())
+    for k, v in g.state_dict().items():                            # same construction order -> same init
+        assert torch.equal(v, og[k]), k
+    for k, v in d.state_dict().items():
+        assert torch.equal(v, od[k]), k
+    assert sum(p.numel() for p in g.parameters()) == 83780 and sum(p.numel() for p in d.parameters()) == 58305
+    before = g.fc1.weight.clone()
+    g.weight_init(mean=0.0, std=0.02)                              # a no-op for nn.Linear (gan.py:15-18)
+    assert torch.equal(g.fc1.weight, before)
+    assert Decoder(noise_dim=16).fc1.in_features == 272
+
+
+def test_flat_parameter_views_and_rebinding():
+    from ndivplanning_amd.models.gan import Discriminator
+    d = Discriminator()
+    flat = d.flat_parameters()
+    assert flat.numel() == 58305 and d.fc1.weight.data_ptr() == flat.data_ptr()
+    with torch.no_grad():
+        flat.zero_()
+    assert float(d.fc4.bias.abs().sum()) == 0.0                    # parameters ARE the flat buffer
+    sd = {k: torch.ones_like(v) for k, v in d.state_dict().items()}
+    d.load_state_dict(sd)                                          # copies in place: still the same buffer
+    assert float(d.flat_parameters().min()) == 1.0 and d.flat_parameters().data_ptr() == flat.data_ptr()
+    d.double().float()                                             # storages replaced -> views rebuilt
+    assert d.flat_parameters().data_ptr() == d.fc1.weight.data_ptr()
+
+
+def test_whole_module_pickles_use_the_reference_class_path():
+    import models.gan as shim                                       # the reference's import name
+    dec = shim.Decoder(noise_dim=2)
+    dec.flat_parameters()
+    buf = io.BytesIO()
+    torch.save(dec, buf)                                            # train_gan.py:254-266 saves whole modules
+    assert b"models.gan" in buf.getvalue() and "_flat" not in dec.__getstate__()
+    buf.seek(0)
+    back = torch.load(buf, weights_only=False)
+    assert isinstance(back, shim.Decoder) and back.noise_dim == 2
+    assert torch.equal(back.fc3.weight, dec.fc3.weight)
+
+
+# ------------------------------------------------------------------ data-parallel helpers
+def test_shard_bounds():
+    from ndivplanning_amd import dp
+    assert [dp.shard_bounds(256, r, 8) for r in (0, 7)] == [(0, 32), (224, 256)]
+    with pytest.raises(ValueError):
+        dp.shard_bounds(10, 0, 4)
+
+
+def test_run_step_order():
+    from ndivplanning_amd import dp
+    log = []
+
+    class B:
+        def d_grads(self, first):
+            log.append("d%d" % first); return "gd"
+        def apply_d(self, g):
+            log.append("ad")
+        def g_grads(self):
+            log.append("g"); return "gg"
+        def apply_g(self, g):
+            log.append("ag")
+    dp.run_step(B(), lambda g: log.append("r:" + g), discrim_steps=2)
+    assert log == ["d1", "r:gd", "ad", "d0", "r:gd", "ad", "g", "r:gg", "ag"]

@@ -1,0 +1,7 @@
+#!/usr/bin/env python3
+"""Drop-in entry point with the reference's name and CLI (`python train_gan.py --config-file
+config/default.yaml ...`); the implementation is ndivplanning_amd/train_gan.py."""
+from ndivplanning_amd.train_gan import denorm, main, norm, train  # noqa: F401
+
+if __name__ == "__main__":
+    main()
