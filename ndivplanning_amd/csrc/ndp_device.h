@@ -113,18 +113,71 @@ __device__ __forceinline__ f32x4 ldg4(const float* p) {
 //   With the native [out][in] layout every quad of lanes touches 4 different cache lines
 //   (lane = weight row) and the per-CU L1 tag rate, not L2 or the MFMA pipe, sets the pace:
 //   measured 12 B/clk/CU native vs ~20 B/clk/CU packed on the 131 KB layers.
-// Caller synchronises before (X ready) and after (Y ready).
-template <int RT, int IN, int OUT, int ACT, int WALIGN, bool PACKED = false>
-__device__ __forceinline__ void layer_fwd(const float* X, int ldx,
-                                          const float* __restrict__ Wm, int ldw,
+//
+// The layer is split in two so that a kernel can issue layer l+1's first weight loads BEFORE
+// it computes layer l (they fly across the barrier between the layers):
+//   FwdW::preload   bias, tail weights and the first PF k-steps of the weight ring -> registers
+//   layer_fwd_run   the k-loop (keeps the ring PF steps ahead), tail step, epilogue to LDS
+// The loop is fully unrolled, so ring slots are static registers and each load is issued
+// ~PF*4*RT*NT MFMAs (>= 1,000 cycles) before its use; an L2 / Infinity-Cache hit costs 500-900.
+template <int IN, int OUT, int WALIGN, bool PACKED>
+struct FwdW {
+  static constexpr int NT = OUT / 64;
+  static constexpr int NIT = IN / 16;
+  static constexpr int PF0 = 96 / (4 * NT);
+  static constexpr int PF = PF0 < NIT ? PF0 : NIT;
+  f32x4 ring[PF][NT];
+  f32x4 wtail[NT];
+  float bias_r[NT];
+  const float* wbase;   // lane's base address (native: its weight row + 4q; packed: + 4*lane)
+  int ldw;
+
+  __device__ __forceinline__ f32x4 frag(int n, int t) const {
+    if (PACKED) {
+      const int wave = threadIdx.x >> 6;
+      return ldg4<4>(wbase + (size_t)((wave * NT + n) * NIT + t) * 256);
+    }
+    return ldg4<WALIGN>(wbase + (size_t)(n * 16) * ldw + 16 * t);
+  }
+
+  __device__ __forceinline__ void preload(const float* __restrict__ Wm, int ldw_,
                                           const float* __restrict__ bias,
-                                          float* Y, int ldy,
-                                          const float* Xt, int ldt, int tail_n,
-                                          const float* __restrict__ Wt) {
-  static_assert(IN % 16 == 0 && OUT % 64 == 0, "layer_fwd shape");
-  constexpr int NT = OUT / 64;
+                                          const float* __restrict__ Wt, int tail_n) {
+    static_assert(IN % 16 == 0 && OUT % 64 == 0, "layer_fwd shape");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int col0 = wave * (OUT / 4);
+    ldw = ldw_;
+    wbase = PACKED ? Wm + 4 * lane : Wm + (size_t)(col0 + c) * ldw_ + 4 * q;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int col = col0 + n * 16 + c;
+      bias_r[n] = bias[col];
+      wtail[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (Wt != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (4 * q + j < tail_n) wtail[n][j] = Wt[(size_t)col * ldw_ + 4 * q + j];
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) ring[p][n] = frag(n, p);
+    pin_vmem();
+  }
+};
+
+template <int RT, int IN, int OUT, int ACT, int WALIGN, bool PACKED>
+__device__ __forceinline__ void layer_fwd_run(FwdW<IN, OUT, WALIGN, PACKED>& w,
+                                              const float* X, int ldx, float* Y, int ldy,
+                                              const float* Xt, int ldt) {
+  constexpr int NT = OUT / 64, NIT = IN / 16;
+  constexpr int PF = FwdW<IN, OUT, WALIGN, PACKED>::PF;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
+  const int col0 = wave * (OUT / 4);
+  const float* xp = X + c * ldx + 4 * q;
 
   f32x4 acc[RT][NT];
 #pragma unroll
@@ -132,52 +185,14 @@ __device__ __forceinline__ void layer_fwd(const float* X, int ldx,
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[r][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int col0 = wave * (OUT / 4);
-  const float* wp = Wm + (size_t)(col0 + c) * ldw + 4 * q;
-  const float* xp = X + c * ldx + 4 * q;
-
-  // epilogue operand (bias) and the "tail" weight columns are fetched first so that their
-  // latency hides under the main loop.  The tail (<= 16 extra inputs: noise / action) is one
-  // more 16-wide k-step with masked weights; Xt rows are zero-padded to 16 in LDS.
-  float bias_r[NT];
-  f32x4 wtail[NT];
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int col = col0 + n * 16 + c;
-    bias_r[n] = bias[col];
-    wtail[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (Xt != nullptr) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (4 * q + j < tail_n) wtail[n][j] = Wt[(size_t)col * ldw + 4 * q + j];
-    }
-  }
-
-  // Weight fragments are prefetched PF k-steps ahead in a register ring: the loop is fully
-  // unrolled, so ring slots are static registers and each load is issued ~PF*4*RT*NT MFMAs
-  // (>= 1,000 cycles) before its use -- an L2 / Infinity-Cache hit costs 500-900 cycles.
-  constexpr int NIT = IN / 16;
-  constexpr int PF0 = 96 / (4 * NT);
-  constexpr int PF = PF0 < NIT ? PF0 : NIT;
-  f32x4 ring[PF][NT];
-  auto wfrag = [&](int n, int t) -> f32x4 {
-    if (PACKED) return ldg4<4>(Wm + ((size_t)((wave * NT + n) * NIT + t) * 64 + lane) * 4);
-    return ldg4<WALIGN>(wp + (size_t)(n * 16) * ldw + 16 * t);
-  };
-#pragma unroll
-  for (int p = 0; p < PF; ++p)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) ring[p][n] = wfrag(n, p);
-  pin_vmem();
-
 #pragma unroll
   for (int t = 0; t < NIT; ++t) {
     f32x4 bv[NT], av[RT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) bv[n] = ring[t % PF][n];
+    for (int n = 0; n < NT; ++n) bv[n] = w.ring[t % PF][n];
     if (t + PF < NIT) {
 #pragma unroll
-      for (int n = 0; n < NT; ++n) ring[t % PF][n] = wfrag(n, t + PF);
+      for (int n = 0; n < NT; ++n) w.ring[t % PF][n] = w.frag(n, t + PF);
       pin_vmem();
     }
 #pragma unroll
@@ -190,6 +205,8 @@ __device__ __forceinline__ void layer_fwd(const float* X, int ldx,
         for (int n = 0; n < NT; ++n) acc[r][n] = mfma16(av[r][s], bv[n][s], acc[r][n]);
   }
 
+  // the "tail" (<= 16 extra inputs: noise / action) is one more 16-wide k-step with masked
+  // weights; Xt rows are zero-padded to 16 in LDS
   if (Xt != nullptr) {
     f32x4 at[RT];
 #pragma unroll
@@ -199,7 +216,7 @@ __device__ __forceinline__ void layer_fwd(const float* X, int ldx,
 #pragma unroll
       for (int r = 0; r < RT; ++r)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[r][n] = mfma16(at[r][s], wtail[n][s], acc[r][n]);
+        for (int n = 0; n < NT; ++n) acc[r][n] = mfma16(at[r][s], w.wtail[n][s], acc[r][n]);
   }
 
 #pragma unroll
@@ -210,7 +227,7 @@ __device__ __forceinline__ void layer_fwd(const float* X, int ldx,
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = r * 16 + 4 * q + i;
-        Y[row * ldy + col] = act_fwd<ACT>(acc[r][n][i] + bias_r[n]);
+        Y[row * ldy + col] = act_fwd<ACT>(acc[r][n][i] + w.bias_r[n]);
       }
   }
 }
@@ -224,32 +241,20 @@ __device__ __forceinline__ void layer_fwd(const float* X, int ldx,
 //   pairs element s of the lane's dY vector with weight row j.
 //   PACKED: W is the dgrad_pack_offset copy: lane l of wave w reads its 4V floats of step t
 //   at ((w*NIT + t)*64 + l)*4V.
-template <int RT, int IN, int OUT, int ACT, bool PACKED = false>
-__device__ __forceinline__ void layer_dgrad(const float* dY, int ldd,
-                                            const float* __restrict__ W, int ldw,
-                                            float* H, int ldh) {
-  static_assert((IN == 64 || IN == 128) && OUT % 16 == 0, "layer_dgrad shape");
-  constexpr int V = IN / 64;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = lane & 15, q = lane >> 4;
-
-  f32x4 acc[RT][V];
-#pragma unroll
-  for (int r = 0; r < RT; ++r)
-#pragma unroll
-    for (int v = 0; v < V; ++v) acc[r][v] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int colbase = wave * 16 * V + V * c;
-  const float* wp = W + (size_t)(4 * q) * ldw + colbase;
-  const float* dp = dY + c * ldd + 4 * q;
-
-  constexpr int NIT = OUT / 16;
-  constexpr int PF0 = 96 / (4 * V);
-  constexpr int PF = PF0 < NIT ? PF0 : NIT;
+// Split like the forward layer: DgW::preload issues the first PF steps, layer_dgrad_run computes.
+template <int IN, int OUT, bool PACKED>
+struct DgW {
+  static constexpr int V = IN / 64;
+  static constexpr int NIT = OUT / 16;
+  static constexpr int PF0 = 96 / (4 * V);
+  static constexpr int PF = PF0 < NIT ? PF0 : NIT;
   float ring[PF][4][V];
-  auto load_step = [&](int t, float (&dst)[4][V]) {
+  const float* wbase;
+  int ldw;
+
+  __device__ __forceinline__ void load_step(int t, float (&dst)[4][V]) const {
     if (PACKED) {
-      const float* p = W + ((size_t)(wave * NIT + t) * 64 + lane) * (4 * V);
+      const float* p = wbase + (size_t)t * 64 * (4 * V);
 #pragma unroll
       for (int h = 0; h < V; ++h) {
         const f32x4 x = *reinterpret_cast<const f32x4*>(p + 4 * h);
@@ -260,7 +265,7 @@ __device__ __forceinline__ void layer_dgrad(const float* dY, int ldd,
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const float* p = wp + (size_t)(16 * t + s) * ldw;
+      const float* p = wbase + (size_t)(16 * t + s) * ldw;
       if (V == 2) {
         f32x2 v2 = *reinterpret_cast<const f32x2*>(p);
         dst[s][0] = v2[0];
@@ -269,10 +274,36 @@ __device__ __forceinline__ void layer_dgrad(const float* dY, int ldd,
         dst[s][0] = *p;
       }
     }
-  };
+  }
+
+  __device__ __forceinline__ void preload(const float* __restrict__ W, int ldw_) {
+    static_assert((IN == 64 || IN == 128) && OUT % 16 == 0, "layer_dgrad shape");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    ldw = ldw_;
+    wbase = PACKED ? W + ((size_t)wave * NIT * 64 + lane) * (4 * V)
+                   : W + (size_t)(4 * q) * ldw_ + wave * 16 * V + V * c;
 #pragma unroll
-  for (int p = 0; p < PF; ++p) load_step(p, ring[p]);
-  pin_vmem();
+    for (int p = 0; p < PF; ++p) load_step(p, ring[p]);
+    pin_vmem();
+  }
+};
+
+template <int RT, int IN, int OUT, int ACT, bool PACKED>
+__device__ __forceinline__ void layer_dgrad_run(DgW<IN, OUT, PACKED>& w, const float* dY, int ldd,
+                                                float* H, int ldh) {
+  constexpr int V = IN / 64, NIT = OUT / 16;
+  constexpr int PF = DgW<IN, OUT, PACKED>::PF;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int colbase = wave * 16 * V + V * c;
+  const float* dp = dY + c * ldd + 4 * q;
+
+  f32x4 acc[RT][V];
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[r][v] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
   for (int t = 0; t < NIT; ++t) {
@@ -281,9 +312,9 @@ __device__ __forceinline__ void layer_dgrad(const float* dY, int ldd,
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int v = 0; v < V; ++v) bv[s][v] = ring[t % PF][s][v];
+      for (int v = 0; v < V; ++v) bv[s][v] = w.ring[t % PF][s][v];
     if (t + PF < NIT) {
-      load_step(t + PF, ring[t % PF]);
+      w.load_step(t + PF, w.ring[t % PF]);
       pin_vmem();
     }
 #pragma unroll

@@ -21,6 +21,8 @@ namespace ndp {
 // kernel reads.  The shipped library contains no stamp.
 #ifdef NDP_STAMPS
 __device__ unsigned long long* g_stamps = nullptr;
+__device__ int g_stamp_kernel = 0;   // which kernel flushes: 1 k_g_fwd, 2 k_d, 3 k_g_bwd, 4 k_wgrad (0 = any)
+#define NDP_STAMP_ON(id) (g_stamps != nullptr && (g_stamp_kernel == 0 || g_stamp_kernel == (id)))
 // stamps are kept in LDS (a global store per stamp would sit in the wave's vmcnt queue and
 // delay the next counted wait) and flushed by NDP_STAMP_FLUSH at the end of the kernel
 #define NDP_STAMP_DECL __shared__ unsigned long long stamp_lds_[32]
@@ -31,16 +33,16 @@ __device__ unsigned long long* g_stamps = nullptr;
       stamp_lds_[2 * (i) + 1] = wall_clock64();                  \
     }                                                            \
   } while (0)
-#define NDP_STAMP_FLUSH(n)                                                                  \
+#define NDP_STAMP_FLUSH(n, id)                                                              \
   do {                                                                                      \
-    if (threadIdx.x == 0 && g_stamps != nullptr)                                            \
+    if (threadIdx.x == 0 && NDP_STAMP_ON(id))                                               \
       for (int i_ = 0; i_ < 2 * (n); ++i_)                                                  \
         g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + i_] = stamp_lds_[i_]; \
   } while (0)
 #else
 #define NDP_STAMP_DECL
 #define NDP_STAMP(i) do { } while (0)
-#define NDP_STAMP_FLUSH(n) do { } while (0)
+#define NDP_STAMP_FLUSH(n, id) do { } while (0)
 #endif
 
 constexpr int CODE = 256;
@@ -154,6 +156,9 @@ __global__ __launch_bounds__(kThreads) void k_g_fwd(GFwdArgs a) {
   NDP_STAMP_DECL;
   NDP_STAMP(0);
 
+  // each layer's first weight loads are issued one stage early (they fly across the barrier)
+  FwdW<256, 128, W1ALIGN, PK> w1;
+  w1.preload(PK ? n.pf1 : n.w1, n.ld1, n.b1, n.w1 + CODE, n.nz);
   load_code_tile<RT>(Xc, 260, a.code, a.ld_code, a.code_rep, row0, a.m, a.code_vec4 != 0);
   for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {
     const int i = idx / TAILLD, t = idx % TAILLD;
@@ -171,16 +176,22 @@ __global__ __launch_bounds__(kThreads) void k_g_fwd(GFwdArgs a) {
   }
   __syncthreads();
   NDP_STAMP(1);
-  layer_fwd<RT, 256, 128, ACT_RELU, W1ALIGN, PK>(Xc, 260, PK ? n.pf1 : n.w1, n.ld1, n.b1, H1, 132, Xt, TAILLD, n.nz, n.w1 + CODE);
+  FwdW<128, 64, 4, PK> w2;
+  w2.preload(PK ? n.pf2 : n.w2, 128, n.b2, nullptr, 0);
+  layer_fwd_run<RT, 256, 128, ACT_RELU, W1ALIGN, PK>(w1, Xc, 260, H1, 132, Xt, TAILLD);
   __syncthreads();
   NDP_STAMP(2);
-  layer_fwd<RT, 128, 64, ACT_RELU, 4, PK>(H1, 132, PK ? n.pf2 : n.w2, 128, n.b2, H2, 68, nullptr, 0, 0, nullptr);
+  FwdW<64, 128, 4, PK> w3;
+  w3.preload(PK ? n.pf3 : n.w3, 64, n.b3, nullptr, 0);
+  layer_fwd_run<RT, 128, 64, ACT_RELU, 4, PK>(w2, H1, 132, H2, 68, nullptr, 0);
   __syncthreads();
   NDP_STAMP(3);
-  layer_fwd<RT, 64, 128, ACT_RELU, 4, PK>(H2, 68, PK ? n.pf3 : n.w3, 64, n.b3, H3, 132, nullptr, 0, 0, nullptr);
+  FwdW<128, 256, 4, PK> w4;
+  w4.preload(PK ? n.pf4 : n.w4, 128, n.b4, nullptr, 0);
+  layer_fwd_run<RT, 64, 128, ACT_RELU, 4, PK>(w3, H2, 68, H3, 132, nullptr, 0);
   __syncthreads();
   NDP_STAMP(4);
-  layer_fwd<RT, 128, 256, ACT_RELU, 4, PK>(H3, 132, PK ? n.pf4 : n.w4, 128, n.b4, H4, 260, nullptr, 0, 0, nullptr);
+  layer_fwd_run<RT, 128, 256, ACT_RELU, 4, PK>(w4, H3, 132, H4, 260, nullptr, 0);
   __syncthreads();
   NDP_STAMP(5);
   layer_fwd_narrow<RT, 256, 4>(H4, 260, n.w5, n.b5, A, 4);
@@ -198,7 +209,7 @@ __global__ __launch_bounds__(kThreads) void k_g_fwd(GFwdArgs a) {
       *reinterpret_cast<f32x4*>(a.action_hat + row * 4) = *reinterpret_cast<const f32x4*>(A + threadIdx.x * 4);
   }
   NDP_STAMP(7);
-  NDP_STAMP_FLUSH(8);
+  NDP_STAMP_FLUSH(8, 1);
 }
 
 // ================================================================ NDiv (diversity.py)
@@ -363,6 +374,10 @@ __global__ __launch_bounds__(kThreads) void k_d(DArgs a) {
   NDP_STAMP_DECL;
   NDP_STAMP(0);
 
+  // cat([action, code]) (models/gan.py:105): weight columns 0..3 = action (tail), 4..259 = code.
+  // Each layer's first weight loads are issued one stage early (they fly across the barrier).
+  FwdW<256, 64, 4, PK> w1;
+  w1.preload(PK ? n.pf1 : n.w1 + ADIM, 260, n.b1, n.w1, ADIM);
   // the code part of the input is the same for every pass: fetch once, write NP copies
   for (int idx = threadIdx.x; idx < R * 64; idx += kThreads) {
     const int i = idx >> 6, k = 4 * (idx & 63);
@@ -388,14 +403,17 @@ __global__ __launch_bounds__(kThreads) void k_d(DArgs a) {
   }
   __syncthreads();
   NDP_STAMP(1);
-  // cat([action, code]) (models/gan.py:105): weight columns 0..3 = action, 4..259 = code
-  layer_fwd<RTT, 256, 64, ACT_LRELU, 4, PK>(Xc, 260, PK ? n.pf1 : n.w1 + ADIM, 260, n.b1, H1, 68, Xt, TAILLD, ADIM, n.w1);
+  FwdW<64, 128, 4, PK> w2;
+  w2.preload(PK ? n.pf2 : n.w2, 64, n.b2, nullptr, 0);
+  layer_fwd_run<RTT, 256, 64, ACT_LRELU, 4, PK>(w1, Xc, 260, H1, 68, Xt, TAILLD);
   __syncthreads();
   NDP_STAMP(2);
-  layer_fwd<RTT, 64, 128, ACT_LRELU, 4, PK>(H1, 68, PK ? n.pf2 : n.w2, 64, n.b2, H2, 132, nullptr, 0, 0, nullptr);
+  FwdW<128, 256, 4, PK> w3;
+  w3.preload(PK ? n.pf3 : n.w3, 128, n.b3, nullptr, 0);
+  layer_fwd_run<RTT, 64, 128, ACT_LRELU, 4, PK>(w2, H1, 68, H2, 132, nullptr, 0);
   __syncthreads();
   NDP_STAMP(3);
-  layer_fwd<RTT, 128, 256, ACT_LRELU, 4, PK>(H2, 132, PK ? n.pf3 : n.w3, 128, n.b3, H3, 260, nullptr, 0, 0, nullptr);
+  layer_fwd_run<RTT, 128, 256, ACT_LRELU, 4, PK>(w3, H2, 132, H3, 260, nullptr, 0);
   __syncthreads();
   NDP_STAMP(4);
   layer_fwd_narrow<RTT, 256, 1>(H3, 260, n.w4, n.b4, L, 1);
@@ -426,7 +444,7 @@ __global__ __launch_bounds__(kThreads) void k_d(DArgs a) {
   }
   NDP_STAMP(6);
   if (!a.do_backward) {
-    NDP_STAMP_FLUSH(7);
+    NDP_STAMP_FLUSH(7, 2);
     return;
   }
   if (a.h1 != nullptr) {
@@ -445,13 +463,17 @@ __global__ __launch_bounds__(kThreads) void k_d(DArgs a) {
   }
   __syncthreads();
   NDP_STAMP(7);
+  DgW<128, 256, PK> g3;
+  g3.preload(PK ? n.pg3 : n.w3, 128);
   layer_dgrad_narrow<RTT, 256, 1, ACT_LRELU>(DL, 1, n.w4, H3, 260);          // H3 := dY3
   __syncthreads();
   NDP_STAMP(8);
-  layer_dgrad<RTT, 128, 256, ACT_LRELU, PK>(H3, 260, PK ? n.pg3 : n.w3, 128, H2, 132);   // H2 := dY2
+  DgW<64, 128, PK> g2;
+  g2.preload(PK ? n.pg2 : n.w2, 64);
+  layer_dgrad_run<RTT, 128, 256, ACT_LRELU, PK>(g3, H3, 260, H2, 132);       // H2 := dY2
   __syncthreads();
   NDP_STAMP(9);
-  layer_dgrad<RTT, 64, 128, ACT_LRELU, PK>(H2, 132, PK ? n.pg2 : n.w2, 64, H1, 68);      // H1 := dY1
+  layer_dgrad_run<RTT, 64, 128, ACT_LRELU, PK>(g2, H2, 132, H1, 68);         // H1 := dY1
   __syncthreads();
   NDP_STAMP(10);
   if (a.dy1 != nullptr) {
@@ -473,7 +495,7 @@ __global__ __launch_bounds__(kThreads) void k_d(DArgs a) {
     if (row < a.m) a.d_action[row * ADIM + j] = s;
   }
   NDP_STAMP(11);
-  NDP_STAMP_FLUSH(12);
+  NDP_STAMP_FLUSH(12, 2);
 }
 
 // ================================================================ G backward (data path)
@@ -501,6 +523,8 @@ __global__ __launch_bounds__(kThreads) void k_g_bwd(GBwdArgs a) {
   const int64_t row0 = (int64_t)blockIdx.x * R;
   const GNet& n = a.net;
 
+  DgW<128, 256, PK> g4;
+  g4.preload(PK ? n.pg4 : n.w4, 128);
   load_tile<RT, 128>(H1, 132, a.h1 + row0 * 128, 128);
   load_tile<RT, 64>(H2, 68, a.h2 + row0 * 64, 64);
   load_tile<RT, 128>(H3, 132, a.h3 + row0 * 128, 128);
@@ -516,13 +540,17 @@ __global__ __launch_bounds__(kThreads) void k_g_bwd(GBwdArgs a) {
     *reinterpret_cast<f32x4*>(a.dy5 + row * 4) = g;
   }
   __syncthreads();
-  layer_dgrad_narrow<RT, 256, 4, ACT_RELU>(DA, 4, n.w5, H4, 260);     // H4 := dY4
+  layer_dgrad_narrow<RT, 256, 4, ACT_RELU>(DA, 4, n.w5, H4, 260);                // H4 := dY4
   __syncthreads();
-  layer_dgrad<RT, 128, 256, ACT_RELU, PK>(H4, 260, PK ? n.pg4 : n.w4, 128, H3, 132);   // H3 := dY3
+  DgW<64, 128, PK> g3;
+  g3.preload(PK ? n.pg3 : n.w3, 64);
+  layer_dgrad_run<RT, 128, 256, ACT_RELU, PK>(g4, H4, 260, H3, 132);             // H3 := dY3
   __syncthreads();
-  layer_dgrad<RT, 64, 128, ACT_RELU, PK>(H3, 132, PK ? n.pg3 : n.w3, 64, H2, 68);      // H2 := dY2
+  DgW<128, 64, PK> g2;
+  g2.preload(PK ? n.pg2 : n.w2, 128);
+  layer_dgrad_run<RT, 64, 128, ACT_RELU, PK>(g3, H3, 132, H2, 68);               // H2 := dY2
   __syncthreads();
-  layer_dgrad<RT, 128, 64, ACT_RELU, PK>(H2, 68, PK ? n.pg2 : n.w2, 128, H1, 132);     // H1 := dY1
+  layer_dgrad_run<RT, 128, 64, ACT_RELU, PK>(g2, H2, 68, H1, 132);               // H1 := dY1
   __syncthreads();
   store_tile<RT, 128>(a.dy1 + row0 * 128, 128, H1, 132);
   store_tile<RT, 64>(a.dy2 + row0 * 64, 64, H2, 68);
@@ -731,7 +759,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
   else wgrad_block<1, 4, WG_SKINNY_A>(jb, rbeg, rend, slab, smem, wst);
 #ifdef NDP_STAMPS
   NDP_WSTAMP(4);
-  if (threadIdx.x == 0 && g_stamps != nullptr)
+  if (threadIdx.x == 0 && NDP_STAMP_ON(4))
     for (int i_ = 0; i_ < 10; ++i_) g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + i_] = wst[i_];
 #endif
 }

@@ -19,7 +19,9 @@ What differs from the reference, on purpose:
     not loaded; visdom plotting is attempted only if visdom is importable.
 
 Extra YAML keys (all optional): `train_data_path: synthetic:<N>[:codes|images]` for seeded
-synthetic trajectories, `training.gan.noise_source`, `training.gan.use_graph`.
+synthetic trajectories, `training.gan.noise_source`, `training.gan.use_graph`,
+`training.gan.steps_per_launch` (iterations per HIP-graph launch, default 4; the batches of one
+launch are staged into separate input slots, the arithmetic is unchanged).
 """
 import logging
 import os
@@ -103,6 +105,7 @@ def train(config):
                        "(the reference fails at train_gan.py:199 for such a file)")
     noise_source = _get(g, "noise_source", "device")
     use_graph = bool(_get(g, "use_graph", True))
+    steps_per_launch = int(_get(g, "steps_per_launch", 4))
 
     rank, world, local_rank = dp.env_world()
     if not torch.cuda.is_available():
@@ -146,11 +149,24 @@ def train(config):
     trainer = GanTrainer(decoder, discriminator, flat=flat_local, num_sample=num_sample, lr=lr_rate,
                          betas=(0.5, 0.999), pairwise_div_factor=float(div_factor), discrim_steps=dsteps,
                          flat_global=flat_local * world, reduce_fn=dp.sum_all_reduce() if world > 1 else None,
-                         use_graph=use_graph, noise_seed=random_seed * 1000 + rank)
+                         use_graph=use_graph, noise_seed=random_seed * 1000 + rank,
+                         steps_per_launch=steps_per_launch if (world == 1 and use_graph) else 1)
+    group = trainer.nslots
     history = []
     for epoch in range(num_epochs):
         discriminator.train()
         decoder.train()
+        pending = []                         # up to `group` prepared batches -> one graph launch
+
+        def flush():
+            if len(pending) == group and group > 1:
+                trainer.step_many(torch.stack([p[0] for p in pending]), torch.stack([p[1] for p in pending]),
+                                  None if pending[0][2] is None else torch.stack([p[2] for p in pending]))
+            else:
+                for c_, a_, n_ in pending:
+                    trainer.step(c_, a_, n_)
+            del pending[:]
+
         for inputs in loader:
             frames, _states, actions, _goal = inputs
             lo, hi = dp.shard_bounds(batch_size, rank, world)
@@ -161,7 +177,10 @@ def train(config):
             noise = None
             if noise_source == "cpu":                                           # train_gan.py:44
                 noise = torch.FloatTensor(flat_local, num_sample, noise_dim).uniform_().to(device)
-            trainer.step(codes, acts, noise)
+            pending.append((codes, acts, noise))
+            if len(pending) == group:
+                flush()
+        flush()
         sums = dp.reduce_loss_shares(trainer.pop_loss_sums(), device=device)
         d_avg, g_avg, div_avg = (v / len(loader) for v in sums)                 # train_gan.py:209-211
         history.append((d_avg, g_avg, div_avg))

@@ -23,7 +23,7 @@ class GanTrainer:
     def __init__(self, decoder: Decoder, discriminator: Discriminator, *, flat: int, num_sample: int,
                  lr: float = 2e-4, betas=(0.5, 0.999), eps: float = 1e-8, pairwise_div_factor: float = 0.1,
                  discrim_steps: int = 1, flat_global: int = None, reduce_fn=None, use_graph: bool = True,
-                 noise_seed: int = 0):
+                 noise_seed: int = 0, steps_per_launch: int = 1):
         self.lib = _capi.load()
         self.decoder, self.discriminator = decoder, discriminator
         self.noise_dim = decoder.noise_dim
@@ -34,6 +34,10 @@ class GanTrainer:
         self.reduce_fn = reduce_fn
         self.use_graph = bool(use_graph)
         self.noise_seed = int(noise_seed)
+        # A graph replay costs ~8 us of GPU idle time between replays (measured: the gap between
+        # the last kernel of one replay and the first of the next); `steps_per_launch` > 1
+        # captures that many consecutive iterations, each with its own input slot, in one graph.
+        self.nslots = max(1, int(steps_per_launch))
         self.g_flat = decoder.flat_parameters()
         self.d_flat = discriminator.flat_parameters()
         dev = self.g_flat.device
@@ -51,10 +55,12 @@ class GanTrainer:
         self.loss_sums = torch.zeros(4, **f32)
         mpad = _capi.pad_rows(self.m)
         self.action_hat = torch.zeros(mpad, ACTION_DIM, **f32)
-        # static input buffers (graph replay needs fixed addresses)
-        self.codes = torch.zeros(self.flat, CODE_DIM, **f32)
-        self.actions = torch.zeros(self.flat, ACTION_DIM, **f32)
-        self.noise = torch.zeros(self.flat, self.k, self.noise_dim, **f32)
+        # static input buffers (graph replay needs fixed addresses), one slot per captured step;
+        # .codes / .actions / .noise are slot 0
+        self.codes_slots = torch.zeros(self.nslots, self.flat, CODE_DIM, **f32)
+        self.actions_slots = torch.zeros(self.nslots, self.flat, ACTION_DIM, **f32)
+        self.noise_slots = torch.zeros(self.nslots, self.flat, self.k, self.noise_dim, **f32)
+        self.codes, self.actions, self.noise = self.codes_slots[0], self.actions_slots[0], self.noise_slots[0]
         self.cfg = _capi.StepConfig(
             noise_dim=self.noise_dim, num_sample=self.k, flat=self.flat,
             inv_m_global=1.0 / float(self.flat_global * self.k), pairwise_div_factor=float(pairwise_div_factor),
@@ -95,28 +101,33 @@ class GanTrainer:
         self.buf_nosum.loss_sums = None
         self._repack()
 
-    def _phase_a(self, first, device_noise=False, last=True):
-        # device noise: the G forward kernel draws U[0,1) itself and fills self.noise
+    def _phase_a(self, first, device_noise=False, last=True, slot=0):
+        # device noise: the G forward kernel draws U[0,1) itself and fills the slot's noise buffer
         self.cfg.device_noise = 1 if device_noise else 0
         buf = self.buf if last else self.buf_nosum
-        _capi.check(self.lib.ndp_step_d_grads(ctypes.byref(self.cfg), ctypes.byref(buf), _capi.ptr(self.codes),
-                                              _capi.ptr(self.actions), _capi.ptr(self.noise), 1 if first else 0,
+        _capi.check(self.lib.ndp_step_d_grads(ctypes.byref(self.cfg), ctypes.byref(buf),
+                                              _capi.ptr(self.codes_slots[slot]), _capi.ptr(self.actions_slots[slot]),
+                                              _capi.ptr(self.noise_slots[slot]), 1 if first else 0,
                                               _capi.stream_ptr()), "ndp_step_d_grads")
 
-    def _phase_b(self):
-        _capi.check(self.lib.ndp_step_g_grads(ctypes.byref(self.cfg), ctypes.byref(self.buf), _capi.ptr(self.codes),
-                                              _capi.ptr(self.actions), _capi.ptr(self.noise), _capi.stream_ptr()),
+    def _phase_b(self, slot=0):
+        _capi.check(self.lib.ndp_step_g_grads(ctypes.byref(self.cfg), ctypes.byref(self.buf),
+                                              _capi.ptr(self.codes_slots[slot]), _capi.ptr(self.actions_slots[slot]),
+                                              _capi.ptr(self.noise_slots[slot]), _capi.stream_ptr()),
                     "ndp_step_g_grads")
 
     # the step as a list of segments; between segments the data-parallel driver
     # all-reduces the gradient the previous segment produced
-    def _segments(self, device_noise):
+    def _segments(self, device_noise, slot=0):
         segs = []
 
         def seg_d(first, last):
             def run():
-                self._phase_a(first, device_noise, last)
+                self._phase_a(first, device_noise, last, slot)
             return run
+
+        def seg_g():
+            self._phase_b(slot)
 
         def d_update():
             _capi.check(self.lib.ndp_step_apply_adam(ctypes.byref(self.cfg), ctypes.byref(self.buf), 0,
@@ -131,7 +142,7 @@ class GanTrainer:
             segs.append((seg_d(it == 0, it == self.discrim_steps - 1), None if fused else self.d_grad))
             if not fused:
                 segs.append((d_update, None))
-        segs.append((self._phase_b, None if fused else self.g_grad))
+        segs.append((seg_g, None if fused else self.g_grad))
         if not fused:
             segs.append((g_update, None))
         return segs
@@ -162,14 +173,16 @@ class GanTrainer:
         for fn, _ in self._segments(device_noise):
             fn()
 
-    def _build_graphs(self, device_noise):
-        """Capture maximal runs of segments that need no collective in between."""
+    def _build_graphs(self, device_noise, nsteps=1):
+        """Capture maximal runs of segments that need no collective in between; `nsteps`
+        consecutive iterations (input slots 0..nsteps-1) when there is no collective at all."""
         # load the code object / set kernel attributes outside of capture
         tmp = torch.empty(4, dtype=torch.float32, device=self.device)
         _capi.check(self.lib.ndp_uniform_noise(_capi.ptr(tmp), 4, 0, None, _capi.stream_ptr()), "warm-up")
         torch.cuda.synchronize(self.device)
         plan, run = [], []
-        for fn, grad in self._segments(device_noise):
+        all_segments = [sg for slot in range(nsteps) for sg in self._segments(device_noise, slot)]
+        for fn, grad in all_segments:
             run.append(fn)
             if grad is not None:
                 plan.append((run, grad))
@@ -190,14 +203,7 @@ class GanTrainer:
         """One training iteration.  `codes` [flat,256], `actions` [flat,4]: this rank's
         shard (None = keep the buffers' current contents); `noise` [flat,K,nz] or None to
         draw U[0,1) on the device."""
-        if self.g_flat.data_ptr() != self.decoder.flat_parameters().data_ptr() or \
-                self.d_flat.data_ptr() != self.discriminator.flat_parameters().data_ptr():
-            self._bind()
-            self._graphs = None
-        elif self._versions() != self._seen_versions:
-            # somebody wrote the parameters through torch (load_state_dict, copy_, an optimizer):
-            # the kernels' packed copies are stale
-            self._repack()
+        self._check_bindings()
         if codes is not None:
             self.codes.copy_(codes.reshape(self.flat, CODE_DIM), non_blocking=True)
         if actions is not None:
@@ -208,16 +214,52 @@ class GanTrainer:
         if not self.use_graph:
             self._run_eager(device_noise)
             return
-        key = bool(device_noise)
+        self._replay(device_noise, 1)
+
+    def _replay(self, device_noise, nsteps):
+        key = (bool(device_noise), nsteps)
         if self._graphs is None:
             self._graphs = {}
         if key not in self._graphs:
             # capture performs no work; the first replay below is the step itself
-            self._graphs[key] = self._build_graphs(device_noise)
+            self._graphs[key] = self._build_graphs(device_noise, nsteps)
         for g, grad in self._graphs[key]:
             g.replay()
             if grad is not None:
                 self.reduce_fn(grad)
+
+    def step_many(self, codes=None, actions=None, noise=None):
+        """`steps_per_launch` consecutive iterations in ONE graph replay.  codes [n,flat,256],
+        actions [n,flat,4], noise [n,flat,K,nz] (n = steps_per_launch); None keeps what the slots
+        hold (codes/actions) or draws device noise.  With a collective between the phases
+        (data parallel) or without graphs this is a plain loop over the slots."""
+        self._check_bindings()
+        n = self.nslots
+        if codes is not None:
+            self.codes_slots.copy_(codes.reshape(n, self.flat, CODE_DIM), non_blocking=True)
+        if actions is not None:
+            self.actions_slots.copy_(actions.reshape(n, self.flat, ACTION_DIM), non_blocking=True)
+        device_noise = noise is None
+        if not device_noise:
+            self.noise_slots.copy_(noise.reshape(n, self.flat, self.k, self.noise_dim), non_blocking=True)
+        if self.use_graph and self.reduce_fn is None:
+            self._replay(device_noise, n)
+            return
+        for slot in range(n):
+            for fn, grad in self._segments(device_noise, slot):
+                fn()
+                if grad is not None:
+                    self.reduce_fn(grad)
+
+    def _check_bindings(self):
+        if self.g_flat.data_ptr() != self.decoder.flat_parameters().data_ptr() or \
+                self.d_flat.data_ptr() != self.discriminator.flat_parameters().data_ptr():
+            self._bind()
+            self._graphs = None
+        elif self._versions() != self._seen_versions:
+            # somebody wrote the parameters through torch (load_state_dict, copy_, an optimizer):
+            # the kernels' packed copies are stale
+            self._repack()
 
     def losses(self):
         """(D_loss, G_loss, pair_div) of the last step as Python floats (synchronises)."""

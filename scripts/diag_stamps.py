@@ -31,7 +31,8 @@ for _ in range(20):
     tr.step()
 torch.cuda.synchronize()
 stamps = torch.zeros(4096 * 32, dtype=torch.int64, device=dev)
-assert raw.ndp_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr())) == 0
+KID = {"g": 1, "ga": 1, "d": 2, "da": 2, "db": 2, "w": 4, "wa": 4, "wb": 4}
+assert raw.ndp_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()), KID.get(os.environ.get("WHICH", "g"), 0)) == 0
 
 def report(name, fn, nphase, nwg):
     for _ in range(int(os.environ.get("WARM", "0"))):
@@ -62,11 +63,29 @@ if which == "w":
         dis(a, c).sum().backward()
     nch = min((512 + 18) // 19, mpad // 64, 64)
     report("k_wgrad[D, 1 pass] [0 setup,1 main loop,2 lds write,3 reduce+store]", fb, 4, 19 * nch)
+elif which == "wa":
+    # D weight gradient inside the real phase A (2 passes): k_wgrad is the last stamping kernel
+    nch = min(512 // 19, 2 * mpad // 64, 64)
+    report("k_wgrad[D, 2 pass] [0 setup,1 main loop,2 lds write,3 reduce+store]", lambda: tr._phase_a(True), 4, 19 * nch)
+elif which == "wb":
+    nch = min(512 // 26, mpad // 64, 64)
+    tr._phase_a(True)
+    report("k_wgrad[G] [0 setup,1 main loop,2 lds write,3 reduce+store]", lambda: tr._phase_b(), 4, 26 * nch)
+elif which == "ga":
+    report("k_g_fwd in phase A (packed weights) [0 load,1 fc1,2 fc2,3 fc3,4 fc4,5 fc5,6 store]",
+           lambda: tr._phase_a(True), 7, mpad // (16 * rt))
+elif which == "da":
+    report("k_d<1,2> in phase A (packed) [0 load,1 fc1,2 fc2,3 fc3,4 fc4,5 loss,6 store,7 dg4,8 dg3,9 dg2,10 store]",
+           lambda: tr._phase_a(True), 11, mpad // 16)
+elif which == "db":
+    tr._phase_a(True)
+    report("k_d<1,1> in phase B (packed) [0 load,1 fc1,2 fc2,3 fc3,4 fc4,5 loss,6 store,7 dg4,8 dg3,9 dg2,10 store]",
+           lambda: tr._phase_b(), 11, mpad // (16 * rt))
 elif which == "g":
     # phase A launches k_g_fwd first; the k_d launch that follows overwrites the stamp buffer,
     # so call the forward alone through the module API
     z = torch.cat([torch.repeat_interleave(codes, k, dim=0), noise[0].reshape(m, -1)], dim=1).to(dev)
-    report("k_g_fwd  [0 load,1 fc1,2 fc2,3 fc3,4 fc4,5 fc5,6 store]", lambda: dec(z), 7, mpad // (16 * rt))
+    report("k_g_fwd (module path, native weight layout)  [0 load,1 fc1,2 fc2,3 fc3,4 fc4,5 fc5,6 store]", lambda: dec(z), 7, mpad // (16 * rt))
 else:
     a = torch.repeat_interleave(actions, k, dim=0).to(dev).requires_grad_(True)
     c = torch.repeat_interleave(codes, k, dim=0).to(dev)

@@ -363,6 +363,27 @@ def test_graph_replay_is_bitwise_eager():
     assert outs[0][2] == outs[1][2]
 
 
+def test_multi_step_graph_is_bitwise_single_steps():
+    """steps_per_launch=3: one graph replay of three iterations (own input slot each) equals
+    three single-step replays bit for bit."""
+    from ndivplanning_amd.trainer import GanTrainer
+    batches = [O.synthetic_batch(20 + i, 8, 6, steps=1) for i in range(3)]
+    outs = []
+    for spl in (1, 3):
+        g, d = O.init_params(0, 2)
+        dec, dis = _load_modules(g, d, 2)
+        tr = GanTrainer(dec, dis, flat=batches[0][0].shape[0], num_sample=6, steps_per_launch=spl)
+        if spl == 1:
+            for c, a, nz_ in batches:
+                tr.step(c.to(DEV), a.to(DEV), nz_[0].to(DEV))
+        else:
+            tr.step_many(torch.stack([b[0] for b in batches]).to(DEV), torch.stack([b[1] for b in batches]).to(DEV),
+                         torch.stack([b[2][0] for b in batches]).to(DEV))
+        outs.append((tr.g_flat.clone(), tr.d_flat.clone(), tr.losses(), tr.pop_loss_sums()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][2] == outs[1][2] and outs[0][3] == outs[1][3]
+
+
 @pytest.mark.parametrize("batch,k", [(64, 6), (128, 32), (5, 7)])
 def test_free_running_vs_oracle(batch, k):
     """Free-running (no forcing) for 3 steps at BASELINE shapes: BCE losses stay within
