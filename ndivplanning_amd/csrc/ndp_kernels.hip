@@ -578,6 +578,9 @@ __device__ __forceinline__ void adam_advance(int32_t* state, float lr, float b1,
 // Workgroup (job, chunk): the 4 waves take interleaved 4-row steps of the chunk's rows,
 // accumulate in registers, then add their four results through LDS and store one slab.
 enum { WG_FULL = 0, WG_SKINNY_B = 1, WG_SKINNY_A = 2 };
+#ifndef NDP_WGRAD_PFG
+#define NDP_WGRAD_PFG 4     // 4-row steps per prefetch group
+#endif
 
 struct WgradJob {
   const float* A;      // dY block: A[row*lda + j]
@@ -624,7 +627,7 @@ __device__ __forceinline__ void wgrad_block(const WgradJob& jb, int rbeg, int re
   // rows are consumed in groups of PFG 4-row steps; the next group's operands are loaded
   // before the current group's MFMAs (register double buffer), so ~PFG*16 MFMAs (>= 2,000
   // cycles) cover each load's latency.
-  constexpr int PFG = 4;
+  constexpr int PFG = NDP_WGRAD_PFG;
   float av[2][PFG][MT], bv[2][PFG][NT];
   auto load_group = [&](int base, float (&ga)[PFG][MT], float (&gb)[PFG][NT]) {
 #pragma unroll
@@ -791,18 +794,25 @@ __global__ __launch_bounds__(kThreads) void k_reduce_adam(ReduceArgs a) {
   __shared__ float sh[8];
   const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   if (p < a.n) {
-    // fixed summation order (bitwise reproducible); four independent chains keep loads in flight
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+    // fixed summation order (bitwise reproducible); 16 loads are issued before the first add so
+    // that a slab sum costs ~2 memory round trips instead of nchunks/4
     const float* sp = a.slabs + p;
+    float g = 0.f;
     int ch = 0;
-    for (; ch + 4 <= a.nchunks; ch += 4) {
-      g0 += sp[(size_t)(ch + 0) * a.slab_stride];
-      g1 += sp[(size_t)(ch + 1) * a.slab_stride];
-      g2 += sp[(size_t)(ch + 2) * a.slab_stride];
-      g3 += sp[(size_t)(ch + 3) * a.slab_stride];
+    for (; ch + 16 <= a.nchunks; ch += 16) {
+      float t[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t[u] = sp[(size_t)(ch + u) * a.slab_stride];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) g += t[u];
     }
-    for (; ch < a.nchunks; ++ch) g0 += sp[(size_t)ch * a.slab_stride];
-    const float g = (g0 + g1) + (g2 + g3);
+    {
+      float t[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t[u] = (ch + u < a.nchunks) ? sp[(size_t)(ch + u) * a.slab_stride] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) g += t[u];
+    }
     if (a.grad != nullptr) a.grad[p] = g;
     if (a.params != nullptr) {
       const float step_size = reinterpret_cast<const float*>(a.step)[1];
