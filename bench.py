@@ -41,14 +41,15 @@ D_FWD = 64 * 260 + 128 * 64 + 256 * 128 + 256                            # 57,85
 D_DGRAD = 256 + 256 * 128 + 128 * 64                                     # 41,216
 G_DGRAD = 4 * 256 + 256 * 128 + 128 * 64 + 64 * 128                      # 50,176
 KERNEL_MACS_PER_ROW = {
-    "k_g_fwd": G_FWD,
-    "k_d[2 pass fwd+bwd]": 2 * (D_FWD + D_DGRAD),
+    "k_phase_a": G_FWD + 2 * (D_FWD + D_DGRAD),          # G forward + D(real), D(fake) forward/backward data path
     "k_wgrad[D]": 2 * D_FWD,
-    "k_d[fwd+bwd]": D_FWD + D_DGRAD + 4 * 64,
-    "k_g_bwd": G_DGRAD,
+    "k_phase_b": D_FWD + D_DGRAD + 4 * 64 + G_DGRAD,     # D' forward/backward to action_hat + G backward data path
     "k_wgrad[G]": G_FWD,
 }
 assert sum(KERNEL_MACS_PER_ROW.values()) == 629760
+# kernels of the non-fused entry points (repeat D steps, module API); not part of the default step
+KERNEL_MACS_PER_ROW.update({"k_g_fwd": G_FWD, "k_d[2 pass fwd+bwd]": 2 * (D_FWD + D_DGRAD),
+                            "k_d[fwd+bwd]": D_FWD + D_DGRAD + 4 * 64, "k_g_bwd": G_DGRAD})
 
 
 def parse_args():

@@ -558,6 +558,314 @@ __global__ __launch_bounds__(kThreads) void k_g_bwd(GBwdArgs a) {
   store_tile<RT, 256>(a.dy4 + row0 * 256, 256, H4, 260);
 }
 
+// ================================================================ fused row-tile kernels of the step
+// Phase A (train_gan.py:165-183) for one 16-row tile in ONE workgroup: G forward, then D on
+// the real and the fake rows (stacked: 32 LDS rows, one stream of D's weights), BCE, backward
+// data path.  Versus k_g_fwd + k_d<1,2>: one launch and one input-tile load less, action_hat
+// goes from G to D through LDS.  LDS regions are reused as the data dies (78 KB -> 2 workgroups
+// per CU):  XC code tile x2 -> later D.h3 | B1 G.h1, G.h3 -> D.h2 | B2 G.h2 -> D.h1 | B3 G.h4
+struct PhaseAArgs {
+  GNet g; DNet d;
+  const float* code; int code_rep;          // [flat x 256], row r uses code[r / code_rep]
+  const float* noise;                        // [m x nz] input, or null when noise_out != null
+  float* noise_out; uint64_t noise_seed; const int32_t* noise_step;
+  const float* actions; int action_rep;      // ground-truth actions [flat x 4]
+  int64_t m, mpad;
+  float inv_m;
+  float *gh1, *gh2, *gh3, *gh4;              // G activations out [mpad x .]
+  float* action_hat;                         // [m x 4] out
+  float *h1, *h2, *h3, *dy1, *dy2, *dy3, *dl, *xa;   // D buffers for k_wgrad [2*mpad x .]
+  float* loss_partials;                      // [ntiles]
+};
+
+constexpr int phase_a_lds_floats() { return 32 * 260 + 32 * TAILLD + 32 * 132 + 32 * 68 + 16 * 260 + 16 * 4 + 32 + 32 + 8; }
+
+template <bool PK>
+__global__ __launch_bounds__(kThreads) void k_phase_a(PhaseAArgs a) {
+  constexpr int R = 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* XC = smem;                  // 32 x 260
+  float* XT = XC + 32 * 260;         // 32 x 16
+  float* B1 = XT + 32 * TAILLD;      // 32 x 132
+  float* B2 = B1 + 32 * 132;         // 32 x 68
+  float* B3 = B2 + 32 * 68;          // 16 x 260
+  float* A = B3 + 16 * 260;          // 16 x 4
+  float* L = A + 16 * 4;             // 32
+  float* DL = L + 32;                // 32
+  float* red = DL + 32;              // 8
+  const int64_t row0 = (int64_t)blockIdx.x * R;
+  const GNet& g = a.g;
+  const DNet& d = a.d;
+  NDP_STAMP_DECL;
+  NDP_STAMP(0);
+
+  // ---------------- G forward (rows 0..15 of the regions)
+  FwdW<256, 128, 2, PK> gw1;
+  gw1.preload(PK ? g.pf1 : g.w1, g.ld1, g.b1, g.w1 + CODE, g.nz);
+  for (int idx = threadIdx.x; idx < R * 64; idx += kThreads) {
+    const int i = idx >> 6, k = 4 * (idx & 63);
+    const int64_t row = row0 + i;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < a.m) v = *reinterpret_cast<const f32x4*>(a.code + (row / a.code_rep) * CODE + k);
+    *reinterpret_cast<f32x4*>(XC + i * 260 + k) = v;
+    *reinterpret_cast<f32x4*>(XC + (R + i) * 260 + k) = v;       // the fake pass' copy
+  }
+  for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {
+    const int i = idx / TAILLD, t = idx % TAILLD;
+    const int64_t row = row0 + i;
+    float v = 0.f;
+    if (row < a.m && t < g.nz) {
+      if (a.noise_out != nullptr) {
+        v = philox_uniform((uint64_t)(row * g.nz + t), a.noise_seed, (uint32_t)*a.noise_step);
+        a.noise_out[row * g.nz + t] = v;
+      } else {
+        v = a.noise[row * g.nz + t];
+      }
+    }
+    XT[idx] = v;
+  }
+  __syncthreads();
+  NDP_STAMP(1);
+  FwdW<128, 64, 4, PK> gw2;
+  gw2.preload(PK ? g.pf2 : g.w2, 128, g.b2, nullptr, 0);
+  layer_fwd_run<1, 256, 128, ACT_RELU, 2, PK>(gw1, XC, 260, B1, 132, XT, TAILLD);      // h1 -> B1
+  __syncthreads();
+  FwdW<64, 128, 4, PK> gw3;
+  gw3.preload(PK ? g.pf3 : g.w3, 64, g.b3, nullptr, 0);
+  store_tile<1, 128>(a.gh1 + row0 * 128, 128, B1, 132);
+  layer_fwd_run<1, 128, 64, ACT_RELU, 4, PK>(gw2, B1, 132, B2, 68, nullptr, 0);        // h2 -> B2
+  __syncthreads();
+  FwdW<128, 256, 4, PK> gw4;
+  gw4.preload(PK ? g.pf4 : g.w4, 128, g.b4, nullptr, 0);
+  store_tile<1, 64>(a.gh2 + row0 * 64, 64, B2, 68);
+  layer_fwd_run<1, 64, 128, ACT_RELU, 4, PK>(gw3, B2, 68, B1, 132, nullptr, 0);        // h3 -> B1 (h1 is stored)
+  __syncthreads();
+  FwdW<256, 64, 4, PK> dw1;                                                             // D fc1 weights fly early
+  dw1.preload(PK ? d.pf1 : d.w1 + ADIM, 260, d.b1, d.w1, ADIM);
+  store_tile<1, 128>(a.gh3 + row0 * 128, 128, B1, 132);
+  layer_fwd_run<1, 128, 256, ACT_RELU, 4, PK>(gw4, B1, 132, B3, 260, nullptr, 0);      // h4 -> B3
+  __syncthreads();
+  store_tile<1, 256>(a.gh4 + row0 * 256, 256, B3, 260);
+  layer_fwd_narrow<1, 256, 4>(B3, 260, g.w5, g.b5, A, 4);                               // action_hat -> A
+  // real actions -> XT rows 0..15 (the noise there is dead), zero pad
+  for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {
+    const int i = idx / TAILLD, t = idx % TAILLD;
+    const int64_t row = row0 + i;
+    XT[idx] = (row < a.m && t < ADIM) ? a.actions[(row / a.action_rep) * ADIM + t] : 0.f;
+  }
+  __syncthreads();
+  NDP_STAMP(2);
+  for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {                      // fake actions -> XT rows 16..31
+    const int i = idx / TAILLD, t = idx % TAILLD;
+    const int64_t row = row0 + i;
+    XT[(R + i) * TAILLD + t] = (row < a.m && t < ADIM) ? A[i * 4 + t] : 0.f;
+  }
+  if (threadIdx.x < R) {
+    const int64_t row = row0 + threadIdx.x;
+    if (row < a.m)
+      *reinterpret_cast<f32x4*>(a.action_hat + row * 4) = *reinterpret_cast<const f32x4*>(A + threadIdx.x * 4);
+  }
+  __syncthreads();
+
+  // ---------------- D on 16 real + 16 fake rows
+  FwdW<64, 128, 4, PK> dw2;
+  dw2.preload(PK ? d.pf2 : d.w2, 64, d.b2, nullptr, 0);
+  layer_fwd_run<2, 256, 64, ACT_LRELU, 4, PK>(dw1, XC, 260, B2, 68, XT, TAILLD);       // D.h1 -> B2
+  __syncthreads();
+  NDP_STAMP(3);
+  FwdW<128, 256, 4, PK> dw3;
+  dw3.preload(PK ? d.pf3 : d.w3, 128, d.b3, nullptr, 0);
+  layer_fwd_run<2, 64, 128, ACT_LRELU, 4, PK>(dw2, B2, 68, B1, 132, nullptr, 0);       // D.h2 -> B1
+  __syncthreads();
+  layer_fwd_run<2, 128, 256, ACT_LRELU, 4, PK>(dw3, B1, 132, XC, 260, nullptr, 0);     // D.h3 -> XC (code tile is dead)
+  __syncthreads();
+  NDP_STAMP(4);
+  layer_fwd_narrow<2, 256, 1>(XC, 260, d.w4, d.b4, L, 1);
+  __syncthreads();
+  float lsum = 0.f;
+  if (threadIdx.x < 2 * R) {
+    const int ps = threadIdx.x / R;
+    const int64_t row = row0 + (threadIdx.x - ps * R);
+    const float target = ps == 0 ? 1.f : 0.f;                    // real: ones, fake: zeros (train_gan.py:174-181)
+    const float x = L[threadIdx.x];
+    float dl = 0.f;
+    if (row < a.m) {
+      lsum = fmaxf(x, 0.f) - x * target + log1pf(expf(-fabsf(x)));
+      dl = (1.f / (1.f + expf(-x)) - target) * a.inv_m;
+    }
+    DL[threadIdx.x] = dl;
+    a.dl[(int64_t)ps * a.mpad + row] = dl;
+  }
+  {
+    const float tot = block_sum(lsum, red);
+    if (threadIdx.x == 0) a.loss_partials[blockIdx.x] = tot;
+  }
+  NDP_STAMP(5);
+  DgW<128, 256, PK> dg3;
+  dg3.preload(PK ? d.pg3 : d.w3, 128);
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int64_t g0 = (int64_t)ps * a.mpad + row0;
+    store_tile<1, 64>(a.h1 + g0 * 64, 64, B2 + ps * R * 68, 68);
+    store_tile<1, 128>(a.h2 + g0 * 128, 128, B1 + ps * R * 132, 132);
+    store_tile<1, 256>(a.h3 + g0 * 256, 256, XC + ps * R * 260, 260);
+  }
+  if (threadIdx.x < 2 * R) {
+    const int ps = threadIdx.x / R;
+    const int64_t gr = (int64_t)ps * a.mpad + row0 + (threadIdx.x - ps * R);
+    *reinterpret_cast<f32x4*>(a.xa + gr * 4) = *reinterpret_cast<const f32x4*>(XT + threadIdx.x * TAILLD);
+  }
+  __syncthreads();
+  NDP_STAMP(6);
+  layer_dgrad_narrow<2, 256, 1, ACT_LRELU>(DL, 1, d.w4, XC, 260);                      // XC := dY3
+  __syncthreads();
+  DgW<64, 128, PK> dg2;
+  dg2.preload(PK ? d.pg2 : d.w2, 64);
+  layer_dgrad_run<2, 128, 256, ACT_LRELU, PK>(dg3, XC, 260, B1, 132);                  // B1 := dY2
+  __syncthreads();
+  NDP_STAMP(7);
+  layer_dgrad_run<2, 64, 128, ACT_LRELU, PK>(dg2, B1, 132, B2, 68);                    // B2 := dY1
+  __syncthreads();
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int64_t g0 = (int64_t)ps * a.mpad + row0;
+    store_tile<1, 64>(a.dy1 + g0 * 64, 64, B2 + ps * R * 68, 68);
+    store_tile<1, 128>(a.dy2 + g0 * 128, 128, B1 + ps * R * 132, 132);
+    store_tile<1, 256>(a.dy3 + g0 * 256, 256, XC + ps * R * 260, 260);
+  }
+  NDP_STAMP(8);
+  NDP_STAMP_FLUSH(9, 5);
+}
+
+// Phase B (train_gan.py:187-202) for one 16-row tile: D' forward with the updated D, G loss,
+// dLoss/d action_hat, + the NDiv gradient, then G's backward data path.  Versus k_d<1,1> +
+// k_g_bwd: one launch less, dLoss/d action_hat never leaves LDS.  39 KB LDS -> 4 per CU.
+struct PhaseBArgs {
+  GNet g; DNet d;
+  const float* code; int code_rep;
+  const float* action_hat;                   // [m x 4]
+  const float* nd_grad;                      // [m x 4] factor * dNDiv/d action_hat, or null
+  int64_t m;
+  float inv_m;
+  const float *gh1, *gh2, *gh3, *gh4;        // G activations saved by phase A
+  float *dy1, *dy2, *dy3, *dy4, *dy5;        // G pre-activation gradients out [mpad x 128/64/128/256/4]
+  float* loss_partials;                      // [ntiles] raw BCE sums (G loss)
+};
+
+constexpr int phase_b_lds_floats() { return 16 * (260 + TAILLD + 132 + 68 + 132 + 4 + 2) + 8; }
+
+template <bool PK>
+__global__ __launch_bounds__(kThreads) void k_phase_b(PhaseBArgs a) {
+  constexpr int R = 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* XC = smem;                  // 16 x 260: code tile -> D.h3 / dY3 -> G.h4 / dY4
+  float* XT = XC + R * 260;          // 16 x 16 : action_hat
+  float* B1 = XT + R * TAILLD;       // 16 x 132: D.h2 / dY2 -> G.h3 / dY3
+  float* B2 = B1 + R * 132;          // 16 x 68 : D.h1 / dY1 -> G.h2 / dY2
+  float* H1 = B2 + R * 68;           // 16 x 132: G.h1 / dY1
+  float* DA = H1 + R * 132;          // 16 x 4
+  float* L = DA + R * 4;             // 16
+  float* DL = L + R;                 // 16
+  float* red = DL + R;               // 8
+  const int64_t row0 = (int64_t)blockIdx.x * R;
+  const GNet& g = a.g;
+  const DNet& d = a.d;
+
+  FwdW<256, 64, 4, PK> dw1;
+  dw1.preload(PK ? d.pf1 : d.w1 + ADIM, 260, d.b1, d.w1, ADIM);
+  for (int idx = threadIdx.x; idx < R * 64; idx += kThreads) {
+    const int i = idx >> 6, k = 4 * (idx & 63);
+    const int64_t row = row0 + i;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < a.m) v = *reinterpret_cast<const f32x4*>(a.code + (row / a.code_rep) * CODE + k);
+    *reinterpret_cast<f32x4*>(XC + i * 260 + k) = v;
+  }
+  for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {
+    const int i = idx / TAILLD, t = idx % TAILLD;
+    const int64_t row = row0 + i;
+    XT[idx] = (row < a.m && t < ADIM) ? a.action_hat[row * ADIM + t] : 0.f;
+  }
+  load_tile<1, 128>(H1, 132, a.gh1 + row0 * 128, 128);                                   // needed last; region is free
+  __syncthreads();
+  FwdW<64, 128, 4, PK> dw2;
+  dw2.preload(PK ? d.pf2 : d.w2, 64, d.b2, nullptr, 0);
+  layer_fwd_run<1, 256, 64, ACT_LRELU, 4, PK>(dw1, XC, 260, B2, 68, XT, TAILLD);        // D.h1 -> B2
+  __syncthreads();
+  FwdW<128, 256, 4, PK> dw3;
+  dw3.preload(PK ? d.pf3 : d.w3, 128, d.b3, nullptr, 0);
+  layer_fwd_run<1, 64, 128, ACT_LRELU, 4, PK>(dw2, B2, 68, B1, 132, nullptr, 0);        // D.h2 -> B1
+  __syncthreads();
+  layer_fwd_run<1, 128, 256, ACT_LRELU, 4, PK>(dw3, B1, 132, XC, 260, nullptr, 0);      // D.h3 -> XC
+  __syncthreads();
+  layer_fwd_narrow<1, 256, 1>(XC, 260, d.w4, d.b4, L, 1);
+  __syncthreads();
+  float lsum = 0.f;
+  if (threadIdx.x < R) {
+    const int64_t row = row0 + threadIdx.x;
+    const float x = L[threadIdx.x];
+    float dl = 0.f;
+    if (row < a.m) {                                             // target 1: G wants D fooled (train_gan.py:187-190)
+      lsum = fmaxf(x, 0.f) - x + log1pf(expf(-fabsf(x)));
+      dl = (1.f / (1.f + expf(-x)) - 1.f) * a.inv_m;
+    }
+    DL[threadIdx.x] = dl;
+  }
+  {
+    const float tot = block_sum(lsum, red);
+    if (threadIdx.x == 0) a.loss_partials[blockIdx.x] = tot;
+  }
+  DgW<128, 256, PK> dg3;
+  dg3.preload(PK ? d.pg3 : d.w3, 128);
+  layer_dgrad_narrow<1, 256, 1, ACT_LRELU>(DL, 1, d.w4, XC, 260);                       // XC := D.dY3
+  __syncthreads();
+  DgW<64, 128, PK> dg2;
+  dg2.preload(PK ? d.pg2 : d.w2, 64);
+  layer_dgrad_run<1, 128, 256, ACT_LRELU, PK>(dg3, XC, 260, B1, 132);                   // B1 := D.dY2
+  __syncthreads();
+  layer_dgrad_run<1, 64, 128, ACT_LRELU, PK>(dg2, B1, 132, B2, 68);                     // B2 := D.dY1
+  __syncthreads();
+  // dLoss/d action_hat = D.dY1 . W1[:, 0:4] (+ NDiv gradient) -> DA and dy5
+  if (threadIdx.x < R * ADIM) {
+    const int i = threadIdx.x >> 2, j = threadIdx.x & 3;
+    const int64_t row = row0 + i;
+    float s = 0.f;
+#pragma unroll 8
+    for (int o = 0; o < 64; ++o) s = fmaf(B2[i * 68 + o], d.w1[o * 260 + j], s);
+    if (row < a.m) {
+      if (a.nd_grad != nullptr) s += a.nd_grad[row * ADIM + j];
+    } else {
+      s = 0.f;
+    }
+    DA[threadIdx.x] = s;
+    a.dy5[row * ADIM + j] = s;
+  }
+  __syncthreads();
+
+  // ---------------- G backward data path (regions XC, B1, B2 are free again)
+  DgW<128, 256, PK> gg4;
+  gg4.preload(PK ? g.pg4 : g.w4, 128);
+  load_tile<1, 256>(XC, 260, a.gh4 + row0 * 256, 256);
+  load_tile<1, 128>(B1, 132, a.gh3 + row0 * 128, 128);
+  load_tile<1, 64>(B2, 68, a.gh2 + row0 * 64, 64);
+  __syncthreads();
+  layer_dgrad_narrow<1, 256, 4, ACT_RELU>(DA, 4, g.w5, XC, 260);                        // XC := G.dY4
+  __syncthreads();
+  DgW<64, 128, PK> gg3;
+  gg3.preload(PK ? g.pg3 : g.w3, 64);
+  layer_dgrad_run<1, 128, 256, ACT_RELU, PK>(gg4, XC, 260, B1, 132);                    // B1 := G.dY3
+  __syncthreads();
+  DgW<128, 64, PK> gg2;
+  gg2.preload(PK ? g.pg2 : g.w2, 128);
+  store_tile<1, 256>(a.dy4 + row0 * 256, 256, XC, 260);
+  layer_dgrad_run<1, 64, 128, ACT_RELU, PK>(gg3, B1, 132, B2, 68);                      // B2 := G.dY2
+  __syncthreads();
+  store_tile<1, 128>(a.dy3 + row0 * 128, 128, B1, 132);
+  layer_dgrad_run<1, 128, 64, ACT_RELU, PK>(gg2, B2, 68, H1, 132);                      // H1 := G.dY1
+  __syncthreads();
+  store_tile<1, 64>(a.dy2 + row0 * 64, 64, B2, 68);
+  store_tile<1, 128>(a.dy1 + row0 * 128, 128, H1, 132);
+}
+
 // Adam state word: {int32 step, float lr/(1-b1^t), float sqrt(1-b2^t), pad}.  One thread
 // advances it ahead of the kernel that applies the update, so that the fp64 pow() runs once
 // per step instead of once per workgroup.
@@ -603,6 +911,8 @@ struct WgradArgs {
   int64_t slab_stride;
   int32_t* bump;       // Adam state {int32 step; float step_size; float bc2_sqrt; pad} to advance, or null
   float lr, beta1, beta2;
+  int nchunks;
+  NdivArgs nd;         // blocks njobs*nchunks.. : NDiv (cx <= 4, cz <= 2) riding in this launch; nd.n == 0: none
 };
 
 #ifdef NDP_STAMPS
@@ -743,12 +1053,21 @@ constexpr int wgrad_lds_floats() { return kWaves * 64 * 64 + kWaves * 64; }
 
 __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const WgradJob& jb = a.job[blockIdx.x];
-  const int rbeg = blockIdx.y * a.rows_per_chunk;
+  // linear grid: block b = chunk * njobs + job; blocks past njobs*nchunks are NDiv blocks (the
+  // NDiv loss/gradient needs only action_hat and the noise: it runs beside the D weight
+  // gradients on otherwise idle CUs instead of as a kernel of its own)
+  const int nwg = a.njobs * a.nchunks;
+  if ((int)blockIdx.x >= nwg) {
+    ndiv_block<4, 2>(a.nd, (int)blockIdx.x - nwg, smem);
+    return;
+  }
+  const int job_id = blockIdx.x % a.njobs, chunk = blockIdx.x / a.njobs;
+  const WgradJob& jb = a.job[job_id];
+  const int rbeg = chunk * a.rows_per_chunk;
   int rend = rbeg + a.rows_per_chunk;
   rend = rend < a.rows ? rend : a.rows;
-  float* slab = a.slabs + (size_t)blockIdx.y * a.slab_stride;
-  if (a.bump != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+  float* slab = a.slabs + (size_t)chunk * a.slab_stride;
+  if (a.bump != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
     adam_advance(a.bump, a.lr, a.beta1, a.beta2);
   const int kind = jb.kind;   // uniform per workgroup
 #ifdef NDP_STAMPS
@@ -763,7 +1082,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
 #ifdef NDP_STAMPS
   NDP_WSTAMP(4);
   if (threadIdx.x == 0 && NDP_STAMP_ON(4))
-    for (int i_ = 0; i_ < 10; ++i_) g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + i_] = wst[i_];
+    for (int i_ = 0; i_ < 10; ++i_) g_stamps[(size_t)blockIdx.x * 32 + i_] = wst[i_];
 #endif
 }
 
