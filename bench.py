@@ -63,6 +63,8 @@ def parse_args():
     ap.add_argument("--steps-per-launch", type=int, default=8,
                     help="iterations captured per HIP graph (single GPU; each iteration has its own input slot)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="run the data-parallel code path (non-fused Adam + RCCL all-reduce) even with one rank")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
 
@@ -119,13 +121,11 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
+    from ndivplanning_amd import dp
     reduce_fn = None
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
-
-        def reduce_fn(grad):
-            dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+    if world > 1 or args.force_dp:
+        dp.init_process_group(dev, force=args.force_dp)     # RCCL; keeps its banner off stdout
+        reduce_fn = dp.sum_all_reduce()
 
     from ndivplanning_amd import _capi
     from ndivplanning_amd.models.gan import Decoder, Discriminator
@@ -141,7 +141,7 @@ def main():
     dis.load_state_dict(d)
     dec, dis = dec.to(dev), dis.to(dev)
     codes, actions, noise = O.synthetic_batch(1000 + rank, batch, k, nz, steps=1)
-    spl = args.steps_per_launch if (world == 1 and not args.no_graph) else 1
+    spl = args.steps_per_launch if (reduce_fn is None and not args.no_graph) else 1
     tr = GanTrainer(dec, dis, flat=flat, num_sample=k, flat_global=flat * world, reduce_fn=reduce_fn,
                     use_graph=not args.no_graph, noise_seed=rank, steps_per_launch=spl)
 
@@ -210,8 +210,7 @@ def main():
                              "tflops": round(2.0 * macs * m / (us * 1e-6) / 1e12, 3) if macs else None}
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     iters_per_s = args.steps / elapsed
@@ -229,7 +228,7 @@ def main():
                                "batch=%d trajectories per GPU, traj_len=8, num_sample=%d, noise_dim=2" % (batch, k),
                    "rows_per_gpu": m, "global_batch": batch * world, "parallelism": "dp%d" % world,
                    "trajectories_per_sec": round(iters_per_s * batch * world, 1),
-                   "hip_graph": not args.no_graph, "steps_per_graph_launch": spl, "last_losses": {"D": losses[0], "G": losses[1], "ndiv": losses[2]}},
+                   "hip_graph": bool(tr.use_graph), "steps_per_graph_launch": spl if tr.use_graph else 0, "last_losses": {"D": losses[0], "G": losses[1], "ndiv": losses[2]}},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                      "algorithmic_flops_per_launch": dom_flops,
@@ -244,7 +243,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(batch, k, nz, args.cpu_seconds)
         result["cpu_baseline"]["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
     print(json.dumps(result))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -206,7 +206,9 @@ int ndp_step_g_grads(const ndp_step_config *cfg, const ndp_step_buffers *buf,
 int ndp_step_pack_params(const ndp_step_config *cfg, const ndp_step_buffers *buf, void *stream);
 
 /* Non-fused (data-parallel) update: Adam for network `which` (0 = D, 1 = G) from
- * buf->d_grad / buf->g_grad (after the all-reduce), refreshing the packed copies. */
+ * buf->d_grad / buf->g_grad (after the all-reduce), refreshing the packed copies.  Must follow
+ * the ndp_step_d_grads / ndp_step_g_grads call that produced the gradient: that call also
+ * advanced the network's Adam state word (step count and bias corrections). */
 int ndp_step_apply_adam(const ndp_step_config *cfg, const ndp_step_buffers *buf, int which,
                         void *stream);
 

@@ -27,18 +27,45 @@ def env_world():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def init_process_group(device=None):
-    """Initialise torch.distributed for one process per GPU (RCCL) or, without a GPU, gloo."""
+class _stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when its first communicator is created; anything
+    that parses this process' stdout (bench.py's one JSON line) must not see it."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        import sys
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
+def init_process_group(device=None, force=False):
+    """Initialise torch.distributed for one process per GPU (RCCL) or, without a GPU, gloo.
+    `force` creates a one-rank group too (to exercise the data-parallel path on one GPU)."""
     rank, world, _ = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this platform
         backend = os.environ.get("NDP_DIST_BACKEND")      # tests force gloo to run 2 ranks on one GPU
         if backend is None:
             backend = "nccl" if device is not None and torch.device(device).type == "cuda" else "gloo"
+        kw = {}
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            kw = dict(rank=0, world_size=1)
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device(device))
+            with _stdout_to_stderr():
+                dist.init_process_group(backend="nccl", device_id=torch.device(device), **kw)
+                warm = torch.zeros(1, device=torch.device(device))
+                dist.all_reduce(warm)                       # creates the communicator (and the banner) now
+                torch.cuda.synchronize(torch.device(device))
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, **kw)
     return rank, world
 
 

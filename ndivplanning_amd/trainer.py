@@ -32,7 +32,10 @@ class GanTrainer:
         self.m = self.flat * self.k
         self.discrim_steps = int(discrim_steps)
         self.reduce_fn = reduce_fn
-        self.use_graph = bool(use_graph)
+        # With a collective between the phases the step cannot be one graph, and replaying
+        # three graph segments costs more (~8 us of launch gap each) than launching the 8 kernels
+        # eagerly, whose host cost hides behind the GPU work (measured: 136 vs 156 us/step).
+        self.use_graph = bool(use_graph) and reduce_fn is None
         self.noise_seed = int(noise_seed)
         # A graph replay costs ~8 us of GPU idle time between replays (measured: the gap between
         # the last kernel of one replay and the first of the next); `steps_per_launch` > 1
