@@ -1053,21 +1053,27 @@ constexpr int wgrad_lds_floats() { return kWaves * 64 * 64 + kWaves * 64; }
 
 __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  // linear grid: block b = chunk * njobs + job; blocks past njobs*nchunks are NDiv blocks (the
-  // NDiv loss/gradient needs only action_hat and the noise: it runs beside the D weight
-  // gradients on otherwise idle CUs instead of as a kernel of its own)
-  const int nwg = a.njobs * a.nchunks;
-  if ((int)blockIdx.x >= nwg) {
-    ndiv_block<4, 2>(a.nd, (int)blockIdx.x - nwg, smem);
+  // Linear grid with an XCD-aware order: workgroups are dealt round-robin over the 8 XCDs
+  // (b % 8 labels the XCD; speed only, never correctness), and every job of a row chunk reads
+  // the same activation rows, so all jobs of chunk c are given to XCD c % 8: the rows then cross
+  // the fabric once per chunk and the other 18..25 jobs hit that XCD's L2 (PMC: FETCH_SIZE of
+  // k_wgrad[D] 55 MB with the plain order, where each XCD fetched every chunk).
+  // Blocks past the wgrad slots are NDiv blocks (the NDiv loss/gradient needs only action_hat
+  // and the noise: it runs beside the D weight gradients instead of as a kernel of its own).
+  const int slots = 8 * ((a.nchunks + 7) / 8) * a.njobs;
+  if ((int)blockIdx.x >= slots) {
+    ndiv_block<4, 2>(a.nd, (int)blockIdx.x - slots, smem);
     return;
   }
-  const int job_id = blockIdx.x % a.njobs, chunk = blockIdx.x / a.njobs;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int job_id = idx % a.njobs, chunk = xcd + 8 * (idx / a.njobs);
+  if (chunk >= a.nchunks) return;
   const WgradJob& jb = a.job[job_id];
   const int rbeg = chunk * a.rows_per_chunk;
   int rend = rbeg + a.rows_per_chunk;
   rend = rend < a.rows ? rend : a.rows;
   float* slab = a.slabs + (size_t)chunk * a.slab_stride;
-  if (a.bump != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+  if (a.bump != nullptr && blockIdx.x == 0 && threadIdx.x == 0)   // block 0 = (chunk 0, job 0): always live
     adam_advance(a.bump, a.lr, a.beta1, a.beta2);
   const int kind = jb.kind;   // uniform per workgroup
 #ifdef NDP_STAMPS
