@@ -120,11 +120,11 @@ __device__ __forceinline__ f32x4 ldg4(const float* p) {
 //   layer_fwd_run   the k-loop (keeps the ring PF steps ahead), tail step, epilogue to LDS
 // The loop is fully unrolled, so ring slots are static registers and each load is issued
 // ~PF*4*RT*NT MFMAs (>= 1,000 cycles) before its use; an L2 / Infinity-Cache hit costs 500-900.
-template <int IN, int OUT, int WALIGN, bool PACKED>
+template <int IN, int OUT, int WALIGN, bool PACKED, int RING = 96>
 struct FwdW {
   static constexpr int NT = OUT / 64;
   static constexpr int NIT = IN / 16;
-  static constexpr int PF0 = 96 / (4 * NT);
+  static constexpr int PF0 = RING / (4 * NT);      // RING = VGPR budget of the prefetch ring
   static constexpr int PF = PF0 < NIT ? PF0 : NIT;
   f32x4 ring[PF][NT];
   f32x4 wtail[NT];
@@ -168,12 +168,12 @@ struct FwdW {
   }
 };
 
-template <int RT, int IN, int OUT, int ACT, int WALIGN, bool PACKED>
-__device__ __forceinline__ void layer_fwd_run(FwdW<IN, OUT, WALIGN, PACKED>& w,
+template <int RT, int IN, int OUT, int ACT, int WALIGN, bool PACKED, int RING>
+__device__ __forceinline__ void layer_fwd_run(FwdW<IN, OUT, WALIGN, PACKED, RING>& w,
                                               const float* X, int ldx, float* Y, int ldy,
                                               const float* Xt, int ldt) {
   constexpr int NT = OUT / 64, NIT = IN / 16;
-  constexpr int PF = FwdW<IN, OUT, WALIGN, PACKED>::PF;
+  constexpr int PF = FwdW<IN, OUT, WALIGN, PACKED, RING>::PF;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
   const int col0 = wave * (OUT / 4);
@@ -242,11 +242,11 @@ __device__ __forceinline__ void layer_fwd_run(FwdW<IN, OUT, WALIGN, PACKED>& w,
 //   PACKED: W is the dgrad_pack_offset copy: lane l of wave w reads its 4V floats of step t
 //   at ((w*NIT + t)*64 + l)*4V.
 // Split like the forward layer: DgW::preload issues the first PF steps, layer_dgrad_run computes.
-template <int IN, int OUT, bool PACKED>
+template <int IN, int OUT, bool PACKED, int RING = 96>
 struct DgW {
   static constexpr int V = IN / 64;
   static constexpr int NIT = OUT / 16;
-  static constexpr int PF0 = 96 / (4 * V);
+  static constexpr int PF0 = RING / (4 * V);
   static constexpr int PF = PF0 < NIT ? PF0 : NIT;
   float ring[PF][4][V];
   const float* wbase;
@@ -289,11 +289,11 @@ struct DgW {
   }
 };
 
-template <int RT, int IN, int OUT, int ACT, bool PACKED>
-__device__ __forceinline__ void layer_dgrad_run(DgW<IN, OUT, PACKED>& w, const float* dY, int ldd,
+template <int RT, int IN, int OUT, int ACT, bool PACKED, int RING>
+__device__ __forceinline__ void layer_dgrad_run(DgW<IN, OUT, PACKED, RING>& w, const float* dY, int ldd,
                                                 float* H, int ldh) {
   constexpr int V = IN / 64, NIT = OUT / 16;
-  constexpr int PF = DgW<IN, OUT, PACKED>::PF;
+  constexpr int PF = DgW<IN, OUT, PACKED, RING>::PF;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
   const int colbase = wave * 16 * V + V * c;

@@ -580,8 +580,10 @@ struct PhaseAArgs {
 
 constexpr int phase_a_lds_floats() { return 32 * 260 + 32 * TAILLD + 32 * 132 + 32 * 68 + 16 * 260 + 16 * 4 + 32 + 32 + 8; }
 
-template <bool PK>
-__global__ __launch_bounds__(kThreads) void k_phase_a(PhaseAArgs a) {
+// RG = VGPR budget of each weight prefetch ring: 96 keeps a lone workgroup per CU streaming at
+// small M; 32 with a 256-register cap lets two workgroups share a CU at large M.
+template <bool PK, int RG>
+__global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseAArgs a) {
   constexpr int R = 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XC = smem;                  // 32 x 260
@@ -600,7 +602,7 @@ __global__ __launch_bounds__(kThreads) void k_phase_a(PhaseAArgs a) {
   NDP_STAMP(0);
 
   // ---------------- G forward (rows 0..15 of the regions)
-  FwdW<256, 128, 2, PK> gw1;
+  FwdW<256, 128, 2, PK, RG> gw1;
   gw1.preload(PK ? g.pf1 : g.w1, g.ld1, g.b1, g.w1 + CODE, g.nz);
   for (int idx = threadIdx.x; idx < R * 64; idx += kThreads) {
     const int i = idx >> 6, k = 4 * (idx & 63);
@@ -626,21 +628,21 @@ __global__ __launch_bounds__(kThreads) void k_phase_a(PhaseAArgs a) {
   }
   __syncthreads();
   NDP_STAMP(1);
-  FwdW<128, 64, 4, PK> gw2;
+  FwdW<128, 64, 4, PK, RG> gw2;
   gw2.preload(PK ? g.pf2 : g.w2, 128, g.b2, nullptr, 0);
   layer_fwd_run<1, 256, 128, ACT_RELU, 2, PK>(gw1, XC, 260, B1, 132, XT, TAILLD);      // h1 -> B1
   __syncthreads();
-  FwdW<64, 128, 4, PK> gw3;
+  FwdW<64, 128, 4, PK, RG> gw3;
   gw3.preload(PK ? g.pf3 : g.w3, 64, g.b3, nullptr, 0);
   store_tile<1, 128>(a.gh1 + row0 * 128, 128, B1, 132);
   layer_fwd_run<1, 128, 64, ACT_RELU, 4, PK>(gw2, B1, 132, B2, 68, nullptr, 0);        // h2 -> B2
   __syncthreads();
-  FwdW<128, 256, 4, PK> gw4;
+  FwdW<128, 256, 4, PK, RG> gw4;
   gw4.preload(PK ? g.pf4 : g.w4, 128, g.b4, nullptr, 0);
   store_tile<1, 64>(a.gh2 + row0 * 64, 64, B2, 68);
   layer_fwd_run<1, 64, 128, ACT_RELU, 4, PK>(gw3, B2, 68, B1, 132, nullptr, 0);        // h3 -> B1 (h1 is stored)
   __syncthreads();
-  FwdW<256, 64, 4, PK> dw1;                                                             // D fc1 weights fly early
+  FwdW<256, 64, 4, PK, RG> dw1;                                                             // D fc1 weights fly early
   dw1.preload(PK ? d.pf1 : d.w1 + ADIM, 260, d.b1, d.w1, ADIM);
   store_tile<1, 128>(a.gh3 + row0 * 128, 128, B1, 132);
   layer_fwd_run<1, 128, 256, ACT_RELU, 4, PK>(gw4, B1, 132, B3, 260, nullptr, 0);      // h4 -> B3
@@ -668,12 +670,12 @@ __global__ __launch_bounds__(kThreads) void k_phase_a(PhaseAArgs a) {
   __syncthreads();
 
   // ---------------- D on 16 real + 16 fake rows
-  FwdW<64, 128, 4, PK> dw2;
+  FwdW<64, 128, 4, PK, RG> dw2;
   dw2.preload(PK ? d.pf2 : d.w2, 64, d.b2, nullptr, 0);
   layer_fwd_run<2, 256, 64, ACT_LRELU, 4, PK>(dw1, XC, 260, B2, 68, XT, TAILLD);       // D.h1 -> B2
   __syncthreads();
   NDP_STAMP(3);
-  FwdW<128, 256, 4, PK> dw3;
+  FwdW<128, 256, 4, PK, RG> dw3;
   dw3.preload(PK ? d.pf3 : d.w3, 128, d.b3, nullptr, 0);
   layer_fwd_run<2, 64, 128, ACT_LRELU, 4, PK>(dw2, B2, 68, B1, 132, nullptr, 0);       // D.h2 -> B1
   __syncthreads();
@@ -701,7 +703,7 @@ __global__ __launch_bounds__(kThreads) void k_phase_a(PhaseAArgs a) {
     if (threadIdx.x == 0) a.loss_partials[blockIdx.x] = tot;
   }
   NDP_STAMP(5);
-  DgW<128, 256, PK> dg3;
+  DgW<128, 256, PK, RG> dg3;
   dg3.preload(PK ? d.pg3 : d.w3, 128);
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
@@ -719,7 +721,7 @@ __global__ __launch_bounds__(kThreads) void k_phase_a(PhaseAArgs a) {
   NDP_STAMP(6);
   layer_dgrad_narrow<2, 256, 1, ACT_LRELU>(DL, 1, d.w4, XC, 260);                      // XC := dY3
   __syncthreads();
-  DgW<64, 128, PK> dg2;
+  DgW<64, 128, PK, RG> dg2;
   dg2.preload(PK ? d.pg2 : d.w2, 64);
   layer_dgrad_run<2, 128, 256, ACT_LRELU, PK>(dg3, XC, 260, B1, 132);                  // B1 := dY2
   __syncthreads();
@@ -754,8 +756,8 @@ struct PhaseBArgs {
 
 constexpr int phase_b_lds_floats() { return 16 * (260 + TAILLD + 132 + 68 + 132 + 4 + 2) + 8; }
 
-template <bool PK>
-__global__ __launch_bounds__(kThreads) void k_phase_b(PhaseBArgs a) {
+template <bool PK, int RG>
+__global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseBArgs a) {
   constexpr int R = 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XC = smem;                  // 16 x 260: code tile -> D.h3 / dY3 -> G.h4 / dY4
@@ -771,7 +773,7 @@ __global__ __launch_bounds__(kThreads) void k_phase_b(PhaseBArgs a) {
   const GNet& g = a.g;
   const DNet& d = a.d;
 
-  FwdW<256, 64, 4, PK> dw1;
+  FwdW<256, 64, 4, PK, RG> dw1;
   dw1.preload(PK ? d.pf1 : d.w1 + ADIM, 260, d.b1, d.w1, ADIM);
   for (int idx = threadIdx.x; idx < R * 64; idx += kThreads) {
     const int i = idx >> 6, k = 4 * (idx & 63);
@@ -787,11 +789,11 @@ __global__ __launch_bounds__(kThreads) void k_phase_b(PhaseBArgs a) {
   }
   load_tile<1, 128>(H1, 132, a.gh1 + row0 * 128, 128);                                   // needed last; region is free
   __syncthreads();
-  FwdW<64, 128, 4, PK> dw2;
+  FwdW<64, 128, 4, PK, RG> dw2;
   dw2.preload(PK ? d.pf2 : d.w2, 64, d.b2, nullptr, 0);
   layer_fwd_run<1, 256, 64, ACT_LRELU, 4, PK>(dw1, XC, 260, B2, 68, XT, TAILLD);        // D.h1 -> B2
   __syncthreads();
-  FwdW<128, 256, 4, PK> dw3;
+  FwdW<128, 256, 4, PK, RG> dw3;
   dw3.preload(PK ? d.pf3 : d.w3, 128, d.b3, nullptr, 0);
   layer_fwd_run<1, 64, 128, ACT_LRELU, 4, PK>(dw2, B2, 68, B1, 132, nullptr, 0);        // D.h2 -> B1
   __syncthreads();
@@ -814,11 +816,11 @@ __global__ __launch_bounds__(kThreads) void k_phase_b(PhaseBArgs a) {
     const float tot = block_sum(lsum, red);
     if (threadIdx.x == 0) a.loss_partials[blockIdx.x] = tot;
   }
-  DgW<128, 256, PK> dg3;
+  DgW<128, 256, PK, RG> dg3;
   dg3.preload(PK ? d.pg3 : d.w3, 128);
   layer_dgrad_narrow<1, 256, 1, ACT_LRELU>(DL, 1, d.w4, XC, 260);                       // XC := D.dY3
   __syncthreads();
-  DgW<64, 128, PK> dg2;
+  DgW<64, 128, PK, RG> dg2;
   dg2.preload(PK ? d.pg2 : d.w2, 64);
   layer_dgrad_run<1, 128, 256, ACT_LRELU, PK>(dg3, XC, 260, B1, 132);                   // B1 := D.dY2
   __syncthreads();
@@ -842,7 +844,7 @@ __global__ __launch_bounds__(kThreads) void k_phase_b(PhaseBArgs a) {
   __syncthreads();
 
   // ---------------- G backward data path (regions XC, B1, B2 are free again)
-  DgW<128, 256, PK> gg4;
+  DgW<128, 256, PK, RG> gg4;
   gg4.preload(PK ? g.pg4 : g.w4, 128);
   load_tile<1, 256>(XC, 260, a.gh4 + row0 * 256, 256);
   load_tile<1, 128>(B1, 132, a.gh3 + row0 * 128, 128);
@@ -850,11 +852,11 @@ __global__ __launch_bounds__(kThreads) void k_phase_b(PhaseBArgs a) {
   __syncthreads();
   layer_dgrad_narrow<1, 256, 4, ACT_RELU>(DA, 4, g.w5, XC, 260);                        // XC := G.dY4
   __syncthreads();
-  DgW<64, 128, PK> gg3;
+  DgW<64, 128, PK, RG> gg3;
   gg3.preload(PK ? g.pg3 : g.w3, 64);
   layer_dgrad_run<1, 128, 256, ACT_RELU, PK>(gg4, XC, 260, B1, 132);                    // B1 := G.dY3
   __syncthreads();
-  DgW<128, 64, PK> gg2;
+  DgW<128, 64, PK, RG> gg2;
   gg2.preload(PK ? g.pg2 : g.w2, 128);
   store_tile<1, 256>(a.dy4 + row0 * 256, 256, XC, 260);
   layer_dgrad_run<1, 64, 128, ACT_RELU, PK>(gg3, B1, 132, B2, 68);                      // B2 := G.dY2
