@@ -889,7 +889,7 @@ __device__ __forceinline__ void adam_advance(int32_t* state, float lr, float b1,
 // accumulate in registers, then add their four results through LDS and store one slab.
 enum { WG_FULL = 0, WG_SKINNY_B = 1, WG_SKINNY_A = 2 };
 #ifndef NDP_WGRAD_PFG
-#define NDP_WGRAD_PFG 4     // 4-row steps per prefetch group
+#define NDP_WGRAD_PFG 8     // 4-row steps in the operand prefetch ring
 #endif
 
 struct WgradJob {
@@ -924,7 +924,7 @@ struct WgradArgs {
 #endif
 
 template <int MT, int NT, int KIND>
-__device__ __forceinline__ void wgrad_block(const WgradJob& jb, int rbeg, int rend,
+__device__ __forceinline__ void wgrad_block(const WgradJob& jb, int rbeg, int rend, int row_last,
                                             float* slab, float* smem, unsigned long long* wst) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
@@ -936,68 +936,86 @@ __device__ __forceinline__ void wgrad_block(const WgradJob& jb, int rbeg, int re
 #pragma unroll
     for (int v = 0; v < NT; ++v) acc[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  // rows are consumed in groups of PFG 4-row steps; the next group's operands are loaded
-  // before the current group's MFMAs (register double buffer), so ~PFG*16 MFMAs (>= 2,000
-  // cycles) cover each load's latency.
-  constexpr int PFG = NDP_WGRAD_PFG;
-  float av[2][PFG][MT], bv[2][PFG][NT];
-  auto load_group = [&](int base, float (&ga)[PFG][MT], float (&gb)[PFG][NT]) {
+  // Main loop.  A wave takes rows rbeg + 16 t + 4 wave + q of step t (nsteps steps).  Operands
+  // go through a register ring of PF steps: slot p is consumed by step t (t % PF == p) and
+  // refilled at once with step t + PF, so every load is issued PF*16 MFMAs before its use.
+  // Every load is UNconditional (rows past the end are clamped to a valid row and simply never
+  // consumed; narrow operands are loaded from a clamped column and zeroed by a select): a
+  // branch around a load makes hipcc fall back to s_waitcnt vmcnt(0) inside the loop.
+  constexpr int PF = NDP_WGRAD_PFG;
+  const bool plain_b = jb.b_rowdiv == 1 && jb.b_rowmod == 0x7fffffff;   // uniform per workgroup
+  const float b_inv = 1.0f / (float)jb.b_rowdiv;
+  const int nsteps = rend > rbeg ? (rend - rbeg) >> 4 : 0;
+  const int row_first = rbeg + 4 * wave + q;
+  const int ca = KIND == WG_SKINNY_A ? (c < jb.a_cols ? c : jb.a_cols - 1) : 4 * c;
+  const int cb = KIND == WG_SKINNY_B ? (c < jb.b_cols ? c : jb.b_cols - 1) : 4 * c;
+  const bool a_on = KIND != WG_SKINNY_A || c < jb.a_cols;
+  const bool b_on = KIND != WG_SKINNY_B || c < jb.b_cols;
+  f32x4 ra[PF], rb[PF];
+  auto load_a = [&](int t) -> f32x4 {
+    int row = row_first + 16 * t;
+    row = row < row_last ? row : row_last;
+    const float* p = jb.A + (size_t)row * jb.lda + ca;
+    if (KIND == WG_SKINNY_A) {
+      const float v = *p;
+      return f32x4{a_on ? v : 0.f, 0.f, 0.f, 0.f};
+    }
+    return *reinterpret_cast<const f32x4*>(p);
+  };
+  auto load_b = [&](int t) -> f32x4 {
+    int row = row_first + 16 * t;
+    row = row < row_last ? row : row_last;
+    // B row: min(((row mod b_rowmod) / b_rowdiv), b_rowmax).  Most jobs read B by the plain row;
+    // the others (codes, broadcast over the K samples and both passes) wrap at most once and
+    // divide through a float reciprocal + fix-up (rows < 2^24): an integer division costs ~40
+    // VALU issues per step and un-hides the MFMAs.
+    int brow = row;
+    if (!plain_b) {
+      const int x = row >= jb.b_rowmod ? row - jb.b_rowmod : row;
+      int qd = (int)((float)x * b_inv);
+      qd = qd * jb.b_rowdiv > x ? qd - 1 : qd;
+      qd = (qd + 1) * jb.b_rowdiv <= x ? qd + 1 : qd;
+      brow = qd;
+    }
+    brow = brow < jb.b_rowmax ? brow : jb.b_rowmax;
+    const float* p = jb.B + (size_t)brow * jb.ldb + cb;
+    if (KIND == WG_SKINNY_B) {
+      const float v = *p;
+      return f32x4{b_on ? v : 0.f, 0.f, 0.f, 0.f};
+    }
+    if (jb.b_vec) return *reinterpret_cast<const f32x4*>(p);
+    return f32x4{p[0], p[1], p[2], p[3]};
+  };
+  auto mma_step = [&](const f32x4& va, const f32x4& vb) {
 #pragma unroll
-    for (int g = 0; g < PFG; ++g) {
-      const int row = base + 16 * g + q;
-      const bool ok = base + 16 * g < rend;      // wave-uniform
-      if (KIND == WG_SKINNY_A) {
-        ga[g][0] = (ok && c < jb.a_cols) ? jb.A[(size_t)row * jb.lda + c] : 0.f;
-      } else {
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        if (ok) t = *reinterpret_cast<const f32x4*>(jb.A + (size_t)row * jb.lda + 4 * c);
+    for (int u = 0; u < MT; ++u) {
+      bs[u] += va[u];
 #pragma unroll
-        for (int u = 0; u < MT; ++u) ga[g][u] = t[u];
-      }
-      int brow = (row % jb.b_rowmod) / jb.b_rowdiv;
-      brow = brow < jb.b_rowmax ? brow : jb.b_rowmax;
-      if (KIND == WG_SKINNY_B) {
-        gb[g][0] = (ok && c < jb.b_cols) ? jb.B[(size_t)brow * jb.ldb + c] : 0.f;
-      } else {
-        const float* p = jb.B + (size_t)brow * jb.ldb + 4 * c;
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        if (ok) {
-          if (jb.b_vec) {
-            t = *reinterpret_cast<const f32x4*>(p);
-          } else {
-            t[0] = p[0]; t[1] = p[1]; t[2] = p[2]; t[3] = p[3];
-          }
-        }
-#pragma unroll
-        for (int v = 0; v < NT; ++v) gb[g][v] = t[v];
-      }
+      for (int v = 0; v < NT; ++v) acc[u][v] = mfma16(va[u], vb[v], acc[u][v]);
     }
   };
-  auto mma_group = [&](const float (&ga)[PFG][MT], const float (&gb)[PFG][NT]) {
-#pragma unroll
-    for (int g = 0; g < PFG; ++g)
-#pragma unroll
-      for (int u = 0; u < MT; ++u) {
-        bs[u] += ga[g][u];
-#pragma unroll
-        for (int v = 0; v < NT; ++v) acc[u][v] = mfma16(ga[g][u], gb[g][v], acc[u][v]);
-      }
-  };
-  int i0 = rbeg + 4 * wave;
   NDP_WSTAMP(1);
-  load_group(i0, av[0], bv[0]);
-  pin_vmem();
-  while (i0 < rend) {
-    load_group(i0 + 16 * PFG, av[1], bv[1]);
-    pin_vmem();
-    mma_group(av[0], bv[0]);
-    i0 += 16 * PFG;
-    if (i0 >= rend) break;
-    load_group(i0 + 16 * PFG, av[0], bv[0]);
-    pin_vmem();
-    mma_group(av[1], bv[1]);
-    i0 += 16 * PFG;
+#pragma unroll
+  for (int p = 0; p < PF; ++p) {
+    ra[p] = load_a(p);
+    rb[p] = load_b(p);
   }
+  pin_vmem();
+  int t = 0;
+  for (; t + PF <= nsteps; t += PF) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      const f32x4 va = ra[p], vb = rb[p];
+      ra[p] = load_a(t + p + PF);
+      rb[p] = load_b(t + p + PF);
+      pin_vmem();
+      mma_step(va, vb);
+    }
+  }
+  const int rem = nsteps - t;                    // < PF; slots 0..rem-1 hold those steps
+#pragma unroll
+  for (int p = 0; p < PF; ++p)
+    if (p < rem) mma_step(ra[p], rb[p]);
   NDP_WSTAMP(2);
   // ---- cross-wave reduction through LDS: tile image [JR][KC] per wave
   constexpr int JR = KIND == WG_SKINNY_A ? 16 : 64;
@@ -1084,9 +1102,9 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
 #else
   unsigned long long* wst = nullptr;
 #endif
-  if (kind == WG_FULL) wgrad_block<4, 4, WG_FULL>(jb, rbeg, rend, slab, smem, wst);
-  else if (kind == WG_SKINNY_B) wgrad_block<4, 1, WG_SKINNY_B>(jb, rbeg, rend, slab, smem, wst);
-  else wgrad_block<1, 4, WG_SKINNY_A>(jb, rbeg, rend, slab, smem, wst);
+  if (kind == WG_FULL) wgrad_block<4, 4, WG_FULL>(jb, rbeg, rend, a.rows - 1, slab, smem, wst);
+  else if (kind == WG_SKINNY_B) wgrad_block<4, 1, WG_SKINNY_B>(jb, rbeg, rend, a.rows - 1, slab, smem, wst);
+  else wgrad_block<1, 4, WG_SKINNY_A>(jb, rbeg, rend, a.rows - 1, slab, smem, wst);
 #ifdef NDP_STAMPS
   NDP_WSTAMP(4);
   if (threadIdx.x == 0 && NDP_STAMP_ON(4))
