@@ -31,7 +31,7 @@ for _ in range(20):
     tr.step()
 torch.cuda.synchronize()
 stamps = torch.zeros(4096 * 32, dtype=torch.int64, device=dev)
-KID = {"g": 1, "ga": 1, "d": 2, "da": 2, "db": 2, "w": 4, "wa": 4, "wb": 4}
+KID = {"g": 1, "ga": 1, "d": 2, "da": 2, "db": 2, "w": 4, "wa": 4, "wb": 4, "pa": 5}
 assert raw.ndp_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()), KID.get(os.environ.get("WHICH", "g"), 0)) == 0
 
 def report(name, fn, nphase, nwg):
@@ -71,6 +71,9 @@ elif which == "wb":
     nch = min(512 // 26, mpad // 64, 64)
     tr._phase_a(True)
     report("k_wgrad[G] [0 setup,1 main loop,2 lds write,3 reduce+store]", lambda: tr._phase_b(), 4, 26 * nch)
+elif which == "pa":
+    report("k_phase_a [0 load,1 G fc1..fc4+fc5,2 a_hat->XT,3 D fc1,4 D fc2+fc3,5 D fc4+loss,6 stores,7 dg4+dg3,8 dg2+stores]",
+           lambda: tr._phase_a(True), 8, mpad // 16)
 elif which == "ga":
     report("k_g_fwd in phase A (packed weights) [0 load,1 fc1,2 fc2,3 fc3,4 fc4,5 fc5,6 store]",
            lambda: tr._phase_a(True), 7, mpad // (16 * rt))
