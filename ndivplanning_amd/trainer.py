@@ -80,7 +80,11 @@ class GanTrainer:
 
     # -- plumbing ---------------------------------------------------------------
     def _versions(self):
-        return (self.g_flat._version, self.d_flat._version)
+        # in-place writes through torch bump the version counter of the tensor they go through:
+        # the flat buffers and every parameter view (which keeps a counter of its own)
+        return (self.g_flat._version, self.d_flat._version,
+                tuple(p._version for p in self.decoder._param_list()),
+                tuple(p._version for p in self.discriminator._param_list()))
 
     def _repack(self):
         """Rebuild the lane-ordered weight copies the step kernels read (include/ndp.h)."""

@@ -515,3 +515,84 @@ def test_device_noise_is_uniform_and_counter_based():
     ctr.fill_(1)
     _capi.check(lib.ndp_uniform_noise(_capi.ptr(out), n, 123, _capi.ptr(ctr), _capi.stream_ptr()), "noise")
     assert not torch.equal(a, out)
+
+
+# ------------------------------------------------------------------ full BASELINE sizes, edges
+def test_config5_full_size_step_vs_oracle():
+    """BASELINE config 5 at its GLOBAL size on one GPU: B=1024, K=32 -> FLAT=7,168, M=229,376.
+    One step against the oracle (2 s on the CPU): BCE losses 1e-4, NDiv sum 1e-4 relative
+    (the reference's own fp32-vs-fp64 gap at this size is 7e-8 relative), action_hat 1e-4."""
+    from ndivplanning_amd.trainer import GanTrainer
+    batch, k = 1024, 32
+    codes, actions, noise = O.synthetic_batch(3, batch, k, steps=1)
+    g, d = O.init_params(0, 2)
+    sm = O.StepMath({n: v.clone() for n, v in g.items()}, {n: v.clone() for n, v in d.items()})
+    ref = sm.step(codes, actions, noise[0])
+    dec, dis = _load_modules(g, d, 2)
+    tr = GanTrainer(dec, dis, flat=codes.shape[0], num_sample=k)
+    tr.step(codes.to(DEV), actions.to(DEV), noise[0].to(DEV))
+    d_loss, g_loss, pd = tr.losses()
+    _close(d_loss, ref["d_loss"], 1e-4, "D_loss")
+    _close(g_loss, ref["g_loss"], 1e-4, "G_loss")
+    _ndiv_close(pd, ref["pair_div"].item(), "pair_div")
+    _close(tr.action_hat[:codes.shape[0] * k], ref["action_hat"], 1e-4, "action_hat")
+    # size-independent properties: parameters moved by at most the Adam bound, all finite
+    g0 = _flat(g).to(DEV)
+    moved = (tr.g_flat - g0).abs().max().item()
+    assert 0 < moved <= 2.5 * 2e-4 and torch.isfinite(tr.g_flat).all() and torch.isfinite(tr.d_flat).all()
+
+
+def test_ndiv_is_translation_invariant_and_scale_free():
+    """Properties of diversity.py that hold at any size: adding a constant to every sample of a
+    row, or scaling all samples of x by c > 0, leaves the loss unchanged (normalised distances)."""
+    from ndivplanning_amd import diversity
+    gen = torch.Generator().manual_seed(2)
+    x = (torch.randn(7168, 32, 4, generator=gen) * 0.1).to(DEV)
+    z = torch.rand(7168, 32, 2, generator=gen).to(DEV)
+    base = diversity.compute_pairwise_divergence(x, z).item()
+    shift = torch.randn(7168, 1, 4, generator=gen).to(DEV)
+    assert abs(diversity.compute_pairwise_divergence(x + shift, z).item() - base) <= 2e-4 * base
+    assert abs(diversity.compute_pairwise_divergence(x * 3.0, z).item() - base) <= 2e-4 * base
+    xg = x.clone().requires_grad_(True)
+    diversity.compute_pairwise_divergence(xg, z).backward()
+    # translation invariance <=> the gradients of a row's samples sum to zero
+    assert xg.grad.sum(dim=1).abs().max().item() <= 1e-3 * xg.grad.abs().max().item()
+
+
+def test_limits_are_reported_not_crashed():
+    from ndivplanning_amd import _capi, diversity
+    from ndivplanning_amd.models.gan import Decoder, Discriminator
+    from ndivplanning_amd.trainer import GanTrainer
+    with pytest.raises(_capi.NdpError):                 # K above NDP_MAX_SAMPLES
+        diversity.compute_pairwise_divergence(torch.zeros(1, 257, 4, device=DEV), torch.zeros(1, 257, 2, device=DEV))
+    with pytest.raises(_capi.NdpError):                 # noise_dim above NDP_MAX_NOISE_DIM
+        Decoder(17).to(DEV)(torch.zeros(4, 256 + 17, device=DEV))
+    with pytest.raises(_capi.NdpError):                 # wrong width
+        Decoder(2).to(DEV)(torch.zeros(4, 257, device=DEV))
+    with pytest.raises(_capi.NdpError):
+        GanTrainer(Decoder(2).to(DEV), Discriminator().to(DEV), flat=8, num_sample=300)
+    with pytest.raises(NotImplementedError):            # input gradients are outside the training path
+        Decoder(2).to(DEV)(torch.zeros(4, 258, device=DEV, requires_grad=True))
+
+
+def test_trainer_sees_parameter_writes_made_through_torch():
+    """load_state_dict / in-place writes between steps must reach the kernels' packed copies."""
+    from ndivplanning_amd.trainer import GanTrainer
+    codes, actions, noise = O.synthetic_batch(4, 8, 6, steps=1)
+    g, d = O.init_params(0, 2)
+    g2, d2 = O.init_params(9, 2)
+    dec, dis = _load_modules(g, d, 2)
+    tr = GanTrainer(dec, dis, flat=codes.shape[0], num_sample=6)
+    tr.step(codes.to(DEV), actions.to(DEV), noise[0].to(DEV))
+    dec.load_state_dict(g2)                               # in place: same storage, new values
+    dis.load_state_dict(d2)
+    tr.load_adam_state({"m": torch.zeros_like(tr.g_m), "v": torch.zeros_like(tr.g_v), "t": 0},
+                       {"m": torch.zeros_like(tr.d_m), "v": torch.zeros_like(tr.d_v), "t": 0})
+    tr.step(codes.to(DEV), actions.to(DEV), noise[0].to(DEV))
+    sm = O.StepMath({n: v.clone() for n, v in g2.items()}, {n: v.clone() for n, v in d2.items()})
+    ref = sm.step(codes, actions, noise[0])
+    _close(tr.action_hat[:codes.shape[0] * 6], ref["action_hat"], 1e-4, "action_hat after load_state_dict")
+    _close(tr.losses()[0], ref["d_loss"], 1e-4, "D_loss after load_state_dict")
+    dec2 = dec.to("cpu").to(DEV)                          # storages replaced: the trainer re-binds
+    tr.step(codes.to(DEV), actions.to(DEV), noise[0].to(DEV))
+    assert dec2.flat_parameters().data_ptr() == tr.g_flat.data_ptr()
