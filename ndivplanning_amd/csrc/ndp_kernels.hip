@@ -558,6 +558,33 @@ __global__ __launch_bounds__(kThreads) void k_g_bwd(GBwdArgs a) {
   store_tile<RT, 256>(a.dy4 + row0 * 256, 256, H4, 260);
 }
 
+// Per-tile segment sums of a pre-activation gradient tile for the K-deduplicated fc1 weight
+// gradient: entry (tile*S + s) = sum over the tile's rows r with floor(r / K) == floor(16*tile / K) + s
+// of (dY[r] + dY[r + pass stride]) -- all rows of one entry multiply the SAME code row.
+// dY: LDS tile [NP*16][ld]; out: global [entries_padded][W].  The last tile also zeroes the padding.
+template <int W, int NP>
+__device__ __forceinline__ void store_segment_sums(const float* dY, int ld, float* __restrict__ out,
+                                                   int64_t row0, int K, int S, int entries_padded) {
+  const int tile = blockIdx.x;
+  const int f0 = (int)(row0 / K);
+  for (int idx = threadIdx.x; idx < S * W; idx += kThreads) {
+    const int sgm = idx / W, col = idx - sgm * W;
+    const int64_t lo64 = (int64_t)(f0 + sgm) * K, hi64 = lo64 + K;
+    const int lo = (int)(lo64 > row0 ? lo64 - row0 : 0);
+    const int hi = (int)(hi64 < row0 + 16 ? hi64 - row0 : 16);
+    float acc = 0.f;
+    for (int r = lo; r < hi; ++r) {
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps) acc += dY[(ps * 16 + r) * ld + col];
+    }
+    out[((size_t)tile * S + sgm) * W + col] = acc;
+  }
+  if (blockIdx.x == gridDim.x - 1) {
+    const int first = (int)gridDim.x * S;
+    for (int idx = threadIdx.x; idx < (entries_padded - first) * W; idx += kThreads) out[(size_t)first * W + idx] = 0.f;
+  }
+}
+
 // ================================================================ fused row-tile kernels of the step
 // Phase A (train_gan.py:165-183) for one 16-row tile in ONE workgroup: G forward, then D on
 // the real and the fake rows (stacked: 32 LDS rows, one stream of D's weights), BCE, backward
@@ -576,6 +603,7 @@ struct PhaseAArgs {
   float* action_hat;                         // [m x 4] out
   float *h1, *h2, *h3, *dy1, *dy2, *dy3, *dl, *xa;   // D buffers for k_wgrad [2*mpad x .]
   float* loss_partials;                      // [ntiles]
+  float* dy1seg; int seg_s, seg_entries;     // segment sums of dY1 (real + fake) [seg_entries x 64]
 };
 
 constexpr int phase_a_lds_floats() { return 32 * 260 + 32 * TAILLD + 32 * 132 + 32 * 68 + 16 * 260 + 16 * 4 + 32 + 32 + 8; }
@@ -728,6 +756,7 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseA
   NDP_STAMP(7);
   layer_dgrad_run<2, 64, 128, ACT_LRELU, PK>(dg2, B1, 132, B2, 68);                    // B2 := dY1
   __syncthreads();
+  store_segment_sums<64, 2>(B2, 68, a.dy1seg, row0, a.code_rep, a.seg_s, a.seg_entries);
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
     const int64_t g0 = (int64_t)ps * a.mpad + row0;
@@ -752,6 +781,7 @@ struct PhaseBArgs {
   const float *gh1, *gh2, *gh3, *gh4;        // G activations saved by phase A
   float *dy1, *dy2, *dy3, *dy4, *dy5;        // G pre-activation gradients out [mpad x 128/64/128/256/4]
   float* loss_partials;                      // [ntiles] raw BCE sums (G loss)
+  float* dy1seg; int seg_s, seg_entries;     // segment sums of G's dY1 [seg_entries x 128]
 };
 
 constexpr int phase_b_lds_floats() { return 16 * (260 + TAILLD + 132 + 68 + 132 + 4 + 2) + 8; }
@@ -866,6 +896,7 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseB
   __syncthreads();
   store_tile<1, 64>(a.dy2 + row0 * 64, 64, B2, 68);
   store_tile<1, 128>(a.dy1 + row0 * 128, 128, H1, 132);
+  store_segment_sums<128, 1>(H1, 132, a.dy1seg, row0, a.code_rep, a.seg_s, a.seg_entries);
 }
 
 // Adam state word: {int32 step, float lr/(1-b1^t), float sqrt(1-b2^t), pad}.  One thread
@@ -902,6 +933,11 @@ struct WgradJob {
   int dst_off, dst_ld; // slab[dst_off + j*dst_ld + k]
   int bias_off;        // slab[bias_off + j] = sum_rows dY[row][j], or -1
   int kind;
+  // K-deduplicated jobs (the code columns of fc1): A holds per-tile SEGMENT sums of dY1 -- the rows
+  // of a 16-row tile that share a FLAT row (same code) are pre-summed by the phase kernel, real and
+  // fake pass together -- so the job runs over rows = ntiles*seg_s entries instead of all M rows;
+  // entry e = tile*seg_s + s pairs with code row (16*tile)/seg_k + s.  rows == 0: plain job.
+  int rows, seg_s, seg_k;
 };
 constexpr int kMaxJobs = 28;
 struct WgradArgs {
@@ -943,8 +979,10 @@ __device__ __forceinline__ void wgrad_block(const WgradJob& jb, int rbeg, int re
   // consumed; narrow operands are loaded from a clamped column and zeroed by a select): a
   // branch around a load makes hipcc fall back to s_waitcnt vmcnt(0) inside the loop.
   constexpr int PF = NDP_WGRAD_PFG;
-  const bool plain_b = jb.b_rowdiv == 1 && jb.b_rowmod == 0x7fffffff;   // uniform per workgroup
-  const float b_inv = 1.0f / (float)jb.b_rowdiv;
+  const bool plain_b = jb.rows == 0 && jb.b_rowdiv == 1 && jb.b_rowmod == 0x7fffffff;   // uniform per workgroup
+  const bool seg_b = jb.rows != 0;
+  const float b_inv = 1.0f / (float)(seg_b ? jb.seg_k : jb.b_rowdiv);
+  const float s_inv = 1.0f / (float)(seg_b ? jb.seg_s : 1);
   const int nsteps = rend > rbeg ? (rend - rbeg) >> 4 : 0;
   const int row_first = rbeg + 4 * wave + q;
   const int ca = KIND == WG_SKINNY_A ? (c < jb.a_cols ? c : jb.a_cols - 1) : 4 * c;
@@ -970,7 +1008,17 @@ __device__ __forceinline__ void wgrad_block(const WgradJob& jb, int rbeg, int re
     // divide through a float reciprocal + fix-up (rows < 2^24): an integer division costs ~40
     // VALU issues per step and un-hides the MFMAs.
     int brow = row;
-    if (!plain_b) {
+    if (seg_b) {
+      // entry -> (tile, s) -> code row (16*tile)/K + s; exact divisions by reciprocal + fix-up
+      int tile = (int)((float)row * s_inv);
+      tile = tile * jb.seg_s > row ? tile - 1 : tile;
+      tile = (tile + 1) * jb.seg_s <= row ? tile + 1 : tile;
+      const int x = 16 * tile;
+      int f0 = (int)((float)x * b_inv);
+      f0 = f0 * jb.seg_k > x ? f0 - 1 : f0;
+      f0 = (f0 + 1) * jb.seg_k <= x ? f0 + 1 : f0;
+      brow = f0 + (row - tile * jb.seg_s);
+    } else if (!plain_b) {
       const int x = row >= jb.b_rowmod ? row - jb.b_rowmod : row;
       int qd = (int)((float)x * b_inv);
       qd = qd * jb.b_rowdiv > x ? qd - 1 : qd;
@@ -1089,9 +1137,12 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
   const int job_id = idx % a.njobs, chunk = xcd + 8 * (idx / a.njobs);
   if (chunk >= a.nchunks) return;
   const WgradJob& jb = a.job[job_id];
-  const int rbeg = chunk * a.rows_per_chunk;
-  int rend = rbeg + a.rows_per_chunk;
-  rend = rend < a.rows ? rend : a.rows;
+  // a job's row space: all rows of the step (a.rows), or its own (segment-sum jobs)
+  const int jrows = jb.rows != 0 ? jb.rows : a.rows;
+  const int jrpc = jb.rows != 0 ? (((jb.rows + a.nchunks - 1) / a.nchunks + 15) & ~15) : a.rows_per_chunk;
+  const int rbeg = chunk * jrpc;
+  int rend = rbeg + jrpc;
+  rend = rend < jrows ? rend : jrows;
   float* slab = a.slabs + (size_t)chunk * a.slab_stride;
   if (a.bump != nullptr && blockIdx.x == 0 && threadIdx.x == 0)   // block 0 = (chunk 0, job 0): always live
     adam_advance(a.bump, a.lr, a.beta1, a.beta2);
@@ -1102,9 +1153,9 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
 #else
   unsigned long long* wst = nullptr;
 #endif
-  if (kind == WG_FULL) wgrad_block<4, 4, WG_FULL>(jb, rbeg, rend, a.rows - 1, slab, smem, wst);
-  else if (kind == WG_SKINNY_B) wgrad_block<4, 1, WG_SKINNY_B>(jb, rbeg, rend, a.rows - 1, slab, smem, wst);
-  else wgrad_block<1, 4, WG_SKINNY_A>(jb, rbeg, rend, a.rows - 1, slab, smem, wst);
+  if (kind == WG_FULL) wgrad_block<4, 4, WG_FULL>(jb, rbeg, rend, jrows - 1, slab, smem, wst);
+  else if (kind == WG_SKINNY_B) wgrad_block<4, 1, WG_SKINNY_B>(jb, rbeg, rend, jrows - 1, slab, smem, wst);
+  else wgrad_block<1, 4, WG_SKINNY_A>(jb, rbeg, rend, jrows - 1, slab, smem, wst);
 #ifdef NDP_STAMPS
   NDP_WSTAMP(4);
   if (threadIdx.x == 0 && NDP_STAMP_ON(4))
