@@ -564,8 +564,8 @@ __global__ __launch_bounds__(kThreads) void k_g_bwd(GBwdArgs a) {
 // dY: LDS tile [NP*16][ld]; out: global [entries_padded][W].  The last tile also zeroes the padding.
 template <int W, int NP>
 __device__ __forceinline__ void store_segment_sums(const float* dY, int ld, float* __restrict__ out,
-                                                   int64_t row0, int K, int S, int entries_padded) {
-  const int tile = blockIdx.x;
+                                                   int64_t row0, int K, int S, int entries_padded,
+                                                   int tile, int ntiles) {
   const int f0 = (int)(row0 / K);
   for (int idx = threadIdx.x; idx < S * W; idx += kThreads) {
     const int sgm = idx / W, col = idx - sgm * W;
@@ -579,8 +579,8 @@ __device__ __forceinline__ void store_segment_sums(const float* dY, int ld, floa
     }
     out[((size_t)tile * S + sgm) * W + col] = acc;
   }
-  if (blockIdx.x == gridDim.x - 1) {
-    const int first = (int)gridDim.x * S;
+  if (tile == ntiles - 1) {
+    const int first = ntiles * S;
     for (int idx = threadIdx.x; idx < (entries_padded - first) * W; idx += kThreads) out[(size_t)first * W + idx] = 0.f;
   }
 }
@@ -606,117 +606,152 @@ struct PhaseAArgs {
   float* dy1seg; int seg_s, seg_entries;     // segment sums of dY1 (real + fake) [seg_entries x 64]
 };
 
-constexpr int phase_a_lds_floats() { return 32 * 260 + 32 * TAILLD + 32 * 132 + 32 * 68 + 16 * 260 + 16 * 4 + 32 + 32 + 8; }
+constexpr int phase_a_lds_floats(bool split) {
+  return (split ? 16 : 32) * (260 + TAILLD + 132 + 68 + 2) + 16 * 260 + 16 * 4 + 8;
+}
 
 // RG = VGPR budget of each weight prefetch ring: 96 keeps a lone workgroup per CU streaming at
 // small M; 32 with a 256-register cap lets two workgroups share a CU at large M.
-template <bool PK, int RG>
+// SPLIT (small M, fewer tiles than CUs): the D step's real pass does not depend on G, so it runs
+// in workgroups of its own (blocks ntiles..2*ntiles-1, 16 rows each) on the CUs that have no tile,
+// beside the G-forward + D(fake) workgroups (blocks 0..ntiles-1): the critical path per tile drops
+// from G + 32 D rows to G + 16 D rows.  With more tiles than CUs the stacked form (!SPLIT: 16 real
+// + 16 fake rows share one stream of D's weights) is the better use of a CU.
+template <bool PK, int RG, bool SPLIT>
 __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseAArgs a) {
   constexpr int R = 16;
+  constexpr int NP = SPLIT ? 1 : 2;  // D passes handled by one workgroup
+  constexpr int DR = R * NP;         // D rows in LDS
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* XC = smem;                  // 32 x 260
-  float* XT = XC + 32 * 260;         // 32 x 16
-  float* B1 = XT + 32 * TAILLD;      // 32 x 132
-  float* B2 = B1 + 32 * 132;         // 32 x 68
-  float* B3 = B2 + 32 * 68;          // 16 x 260
+  float* XC = smem;                  // DR x 260
+  float* XT = XC + DR * 260;         // DR x 16
+  float* B1 = XT + DR * TAILLD;      // DR x 132
+  float* B2 = B1 + DR * 132;         // DR x 68
+  float* B3 = B2 + DR * 68;          // 16 x 260
   float* A = B3 + 16 * 260;          // 16 x 4
-  float* L = A + 16 * 4;             // 32
-  float* DL = L + 32;                // 32
-  float* red = DL + 32;              // 8
-  const int64_t row0 = (int64_t)blockIdx.x * R;
+  float* L = A + 16 * 4;             // DR
+  float* DL = L + DR;                // DR
+  float* red = DL + DR;              // 8
+  const int ntiles = SPLIT ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+  const int role = SPLIT ? (int)(blockIdx.x / ntiles) : 0;          // SPLIT: 0 = G + D(fake), 1 = D(real)
+  const int tile = SPLIT ? (int)(blockIdx.x - role * ntiles) : (int)blockIdx.x;
+  const int64_t row0 = (int64_t)tile * R;
   const GNet& g = a.g;
   const DNet& d = a.d;
   NDP_STAMP_DECL;
   NDP_STAMP(0);
 
-  // ---------------- G forward (rows 0..15 of the regions)
-  FwdW<256, 128, 2, PK, RG> gw1;
-  gw1.preload(PK ? g.pf1 : g.w1, g.ld1, g.b1, g.w1 + CODE, g.nz);
-  for (int idx = threadIdx.x; idx < R * 64; idx += kThreads) {
-    const int i = idx >> 6, k = 4 * (idx & 63);
-    const int64_t row = row0 + i;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row < a.m) v = *reinterpret_cast<const f32x4*>(a.code + (row / a.code_rep) * CODE + k);
-    *reinterpret_cast<f32x4*>(XC + i * 260 + k) = v;
-    *reinterpret_cast<f32x4*>(XC + (R + i) * 260 + k) = v;       // the fake pass' copy
-  }
-  for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {
-    const int i = idx / TAILLD, t = idx % TAILLD;
-    const int64_t row = row0 + i;
-    float v = 0.f;
-    if (row < a.m && t < g.nz) {
-      if (a.noise_out != nullptr) {
-        v = philox_uniform((uint64_t)(row * g.nz + t), a.noise_seed, (uint32_t)*a.noise_step);
-        a.noise_out[row * g.nz + t] = v;
-      } else {
-        v = a.noise[row * g.nz + t];
+  FwdW<256, 64, 4, PK, RG> dw1;
+  if (!SPLIT || role == 0) {
+    // ---------------- G forward (rows 0..15 of the regions)
+    FwdW<256, 128, 2, PK, RG> gw1;
+    gw1.preload(PK ? g.pf1 : g.w1, g.ld1, g.b1, g.w1 + CODE, g.nz);
+    for (int idx = threadIdx.x; idx < R * 64; idx += kThreads) {
+      const int i = idx >> 6, k = 4 * (idx & 63);
+      const int64_t row = row0 + i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < a.m) v = *reinterpret_cast<const f32x4*>(a.code + (row / a.code_rep) * CODE + k);
+      *reinterpret_cast<f32x4*>(XC + i * 260 + k) = v;
+      if (!SPLIT) *reinterpret_cast<f32x4*>(XC + (R + i) * 260 + k) = v;       // the fake pass' copy
+    }
+    for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {
+      const int i = idx / TAILLD, t = idx % TAILLD;
+      const int64_t row = row0 + i;
+      float v = 0.f;
+      if (row < a.m && t < g.nz) {
+        if (a.noise_out != nullptr) {
+          v = philox_uniform((uint64_t)(row * g.nz + t), a.noise_seed, (uint32_t)*a.noise_step);
+          a.noise_out[row * g.nz + t] = v;
+        } else {
+          v = a.noise[row * g.nz + t];
+        }
+      }
+      XT[idx] = v;
+    }
+    __syncthreads();
+    NDP_STAMP(1);
+    FwdW<128, 64, 4, PK, RG> gw2;
+    gw2.preload(PK ? g.pf2 : g.w2, 128, g.b2, nullptr, 0);
+    layer_fwd_run<1, 256, 128, ACT_RELU, 2, PK>(gw1, XC, 260, B1, 132, XT, TAILLD);      // h1 -> B1
+    __syncthreads();
+    FwdW<64, 128, 4, PK, RG> gw3;
+    gw3.preload(PK ? g.pf3 : g.w3, 64, g.b3, nullptr, 0);
+    store_tile<1, 128>(a.gh1 + row0 * 128, 128, B1, 132);
+    layer_fwd_run<1, 128, 64, ACT_RELU, 4, PK>(gw2, B1, 132, B2, 68, nullptr, 0);        // h2 -> B2
+    __syncthreads();
+    FwdW<128, 256, 4, PK, RG> gw4;
+    gw4.preload(PK ? g.pf4 : g.w4, 128, g.b4, nullptr, 0);
+    store_tile<1, 64>(a.gh2 + row0 * 64, 64, B2, 68);
+    layer_fwd_run<1, 64, 128, ACT_RELU, 4, PK>(gw3, B2, 68, B1, 132, nullptr, 0);        // h3 -> B1 (h1 is stored)
+    __syncthreads();
+    dw1.preload(PK ? d.pf1 : d.w1 + ADIM, 260, d.b1, d.w1, ADIM);                         // D fc1 weights fly early
+    store_tile<1, 128>(a.gh3 + row0 * 128, 128, B1, 132);
+    layer_fwd_run<1, 128, 256, ACT_RELU, 4, PK>(gw4, B1, 132, B3, 260, nullptr, 0);      // h4 -> B3
+    __syncthreads();
+    store_tile<1, 256>(a.gh4 + row0 * 256, 256, B3, 260);
+    layer_fwd_narrow<1, 256, 4>(B3, 260, g.w5, g.b5, A, 4);                               // action_hat -> A
+    if (!SPLIT) {
+      // real actions -> XT rows 0..15 (the noise there is dead), zero pad
+      for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {
+        const int i = idx / TAILLD, t = idx % TAILLD;
+        const int64_t row = row0 + i;
+        XT[idx] = (row < a.m && t < ADIM) ? a.actions[(row / a.action_rep) * ADIM + t] : 0.f;
       }
     }
-    XT[idx] = v;
+    __syncthreads();
+    NDP_STAMP(2);
+    for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {                      // fake actions -> XT
+      const int i = idx / TAILLD, t = idx % TAILLD;
+      const int64_t row = row0 + i;
+      XT[((NP - 1) * R + i) * TAILLD + t] = (row < a.m && t < ADIM) ? A[i * 4 + t] : 0.f;
+    }
+    if (threadIdx.x < R) {
+      const int64_t row = row0 + threadIdx.x;
+      if (row < a.m)
+        *reinterpret_cast<f32x4*>(a.action_hat + row * 4) = *reinterpret_cast<const f32x4*>(A + threadIdx.x * 4);
+    }
+    __syncthreads();
+  } else {
+    // ---------------- SPLIT, role 1: the real pass' inputs
+    dw1.preload(PK ? d.pf1 : d.w1 + ADIM, 260, d.b1, d.w1, ADIM);
+    for (int idx = threadIdx.x; idx < R * 64; idx += kThreads) {
+      const int i = idx >> 6, k = 4 * (idx & 63);
+      const int64_t row = row0 + i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < a.m) v = *reinterpret_cast<const f32x4*>(a.code + (row / a.code_rep) * CODE + k);
+      *reinterpret_cast<f32x4*>(XC + i * 260 + k) = v;
+    }
+    for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {
+      const int i = idx / TAILLD, t = idx % TAILLD;
+      const int64_t row = row0 + i;
+      XT[idx] = (row < a.m && t < ADIM) ? a.actions[(row / a.action_rep) * ADIM + t] : 0.f;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  NDP_STAMP(1);
-  FwdW<128, 64, 4, PK, RG> gw2;
-  gw2.preload(PK ? g.pf2 : g.w2, 128, g.b2, nullptr, 0);
-  layer_fwd_run<1, 256, 128, ACT_RELU, 2, PK>(gw1, XC, 260, B1, 132, XT, TAILLD);      // h1 -> B1
-  __syncthreads();
-  FwdW<64, 128, 4, PK, RG> gw3;
-  gw3.preload(PK ? g.pf3 : g.w3, 64, g.b3, nullptr, 0);
-  store_tile<1, 128>(a.gh1 + row0 * 128, 128, B1, 132);
-  layer_fwd_run<1, 128, 64, ACT_RELU, 4, PK>(gw2, B1, 132, B2, 68, nullptr, 0);        // h2 -> B2
-  __syncthreads();
-  FwdW<128, 256, 4, PK, RG> gw4;
-  gw4.preload(PK ? g.pf4 : g.w4, 128, g.b4, nullptr, 0);
-  store_tile<1, 64>(a.gh2 + row0 * 64, 64, B2, 68);
-  layer_fwd_run<1, 64, 128, ACT_RELU, 4, PK>(gw3, B2, 68, B1, 132, nullptr, 0);        // h3 -> B1 (h1 is stored)
-  __syncthreads();
-  FwdW<256, 64, 4, PK, RG> dw1;                                                             // D fc1 weights fly early
-  dw1.preload(PK ? d.pf1 : d.w1 + ADIM, 260, d.b1, d.w1, ADIM);
-  store_tile<1, 128>(a.gh3 + row0 * 128, 128, B1, 132);
-  layer_fwd_run<1, 128, 256, ACT_RELU, 4, PK>(gw4, B1, 132, B3, 260, nullptr, 0);      // h4 -> B3
-  __syncthreads();
-  store_tile<1, 256>(a.gh4 + row0 * 256, 256, B3, 260);
-  layer_fwd_narrow<1, 256, 4>(B3, 260, g.w5, g.b5, A, 4);                               // action_hat -> A
-  // real actions -> XT rows 0..15 (the noise there is dead), zero pad
-  for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {
-    const int i = idx / TAILLD, t = idx % TAILLD;
-    const int64_t row = row0 + i;
-    XT[idx] = (row < a.m && t < ADIM) ? a.actions[(row / a.action_rep) * ADIM + t] : 0.f;
-  }
-  __syncthreads();
-  NDP_STAMP(2);
-  for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {                      // fake actions -> XT rows 16..31
-    const int i = idx / TAILLD, t = idx % TAILLD;
-    const int64_t row = row0 + i;
-    XT[(R + i) * TAILLD + t] = (row < a.m && t < ADIM) ? A[i * 4 + t] : 0.f;
-  }
-  if (threadIdx.x < R) {
-    const int64_t row = row0 + threadIdx.x;
-    if (row < a.m)
-      *reinterpret_cast<f32x4*>(a.action_hat + row * 4) = *reinterpret_cast<const f32x4*>(A + threadIdx.x * 4);
-  }
-  __syncthreads();
+  // pass p of this workgroup is global pass gp: stacked: p (0 real, 1 fake); split: role 0 -> fake, role 1 -> real
+  const int gp0 = SPLIT ? 1 - role : 0;
 
-  // ---------------- D on 16 real + 16 fake rows
+  // ---------------- D on DR rows
   FwdW<64, 128, 4, PK, RG> dw2;
   dw2.preload(PK ? d.pf2 : d.w2, 64, d.b2, nullptr, 0);
-  layer_fwd_run<2, 256, 64, ACT_LRELU, 4, PK>(dw1, XC, 260, B2, 68, XT, TAILLD);       // D.h1 -> B2
+  layer_fwd_run<NP, 256, 64, ACT_LRELU, 4, PK>(dw1, XC, 260, B2, 68, XT, TAILLD);      // D.h1 -> B2
   __syncthreads();
   NDP_STAMP(3);
   FwdW<128, 256, 4, PK, RG> dw3;
   dw3.preload(PK ? d.pf3 : d.w3, 128, d.b3, nullptr, 0);
-  layer_fwd_run<2, 64, 128, ACT_LRELU, 4, PK>(dw2, B2, 68, B1, 132, nullptr, 0);       // D.h2 -> B1
+  layer_fwd_run<NP, 64, 128, ACT_LRELU, 4, PK>(dw2, B2, 68, B1, 132, nullptr, 0);      // D.h2 -> B1
   __syncthreads();
-  layer_fwd_run<2, 128, 256, ACT_LRELU, 4, PK>(dw3, B1, 132, XC, 260, nullptr, 0);     // D.h3 -> XC (code tile is dead)
+  layer_fwd_run<NP, 128, 256, ACT_LRELU, 4, PK>(dw3, B1, 132, XC, 260, nullptr, 0);    // D.h3 -> XC (code tile is dead)
   __syncthreads();
   NDP_STAMP(4);
-  layer_fwd_narrow<2, 256, 1>(XC, 260, d.w4, d.b4, L, 1);
+  layer_fwd_narrow<NP, 256, 1>(XC, 260, d.w4, d.b4, L, 1);
   __syncthreads();
   float lsum = 0.f;
-  if (threadIdx.x < 2 * R) {
+  if (threadIdx.x < DR) {
     const int ps = threadIdx.x / R;
+    const int gp = gp0 + ps;
     const int64_t row = row0 + (threadIdx.x - ps * R);
-    const float target = ps == 0 ? 1.f : 0.f;                    // real: ones, fake: zeros (train_gan.py:174-181)
+    const float target = gp == 0 ? 1.f : 0.f;                    // real: ones, fake: zeros (train_gan.py:174-181)
     const float x = L[threadIdx.x];
     float dl = 0.f;
     if (row < a.m) {
@@ -724,7 +759,7 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseA
       dl = (1.f / (1.f + expf(-x)) - target) * a.inv_m;
     }
     DL[threadIdx.x] = dl;
-    a.dl[(int64_t)ps * a.mpad + row] = dl;
+    a.dl[(int64_t)gp * a.mpad + row] = dl;
   }
   {
     const float tot = block_sum(lsum, red);
@@ -734,32 +769,35 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseA
   DgW<128, 256, PK, RG> dg3;
   dg3.preload(PK ? d.pg3 : d.w3, 128);
 #pragma unroll
-  for (int ps = 0; ps < 2; ++ps) {
-    const int64_t g0 = (int64_t)ps * a.mpad + row0;
+  for (int ps = 0; ps < NP; ++ps) {
+    const int64_t g0 = (int64_t)(gp0 + ps) * a.mpad + row0;
     store_tile<1, 64>(a.h1 + g0 * 64, 64, B2 + ps * R * 68, 68);
     store_tile<1, 128>(a.h2 + g0 * 128, 128, B1 + ps * R * 132, 132);
     store_tile<1, 256>(a.h3 + g0 * 256, 256, XC + ps * R * 260, 260);
   }
-  if (threadIdx.x < 2 * R) {
+  if (threadIdx.x < DR) {
     const int ps = threadIdx.x / R;
-    const int64_t gr = (int64_t)ps * a.mpad + row0 + (threadIdx.x - ps * R);
+    const int64_t gr = (int64_t)(gp0 + ps) * a.mpad + row0 + (threadIdx.x - ps * R);
     *reinterpret_cast<f32x4*>(a.xa + gr * 4) = *reinterpret_cast<const f32x4*>(XT + threadIdx.x * TAILLD);
   }
   __syncthreads();
   NDP_STAMP(6);
-  layer_dgrad_narrow<2, 256, 1, ACT_LRELU>(DL, 1, d.w4, XC, 260);                      // XC := dY3
+  layer_dgrad_narrow<NP, 256, 1, ACT_LRELU>(DL, 1, d.w4, XC, 260);                     // XC := dY3
   __syncthreads();
   DgW<64, 128, PK, RG> dg2;
   dg2.preload(PK ? d.pg2 : d.w2, 64);
-  layer_dgrad_run<2, 128, 256, ACT_LRELU, PK>(dg3, XC, 260, B1, 132);                  // B1 := dY2
+  layer_dgrad_run<NP, 128, 256, ACT_LRELU, PK>(dg3, XC, 260, B1, 132);                 // B1 := dY2
   __syncthreads();
   NDP_STAMP(7);
-  layer_dgrad_run<2, 64, 128, ACT_LRELU, PK>(dg2, B1, 132, B2, 68);                    // B2 := dY1
+  layer_dgrad_run<NP, 64, 128, ACT_LRELU, PK>(dg2, B1, 132, B2, 68);                   // B2 := dY1
   __syncthreads();
-  store_segment_sums<64, 2>(B2, 68, a.dy1seg, row0, a.code_rep, a.seg_s, a.seg_entries);
+  // segment sums of dY1 for the K-deduplicated fc1 weight gradient: stacked: real + fake summed
+  // into entries [0, E); split: this pass' half of a [2E] buffer
+  store_segment_sums<64, NP>(B2, 68, a.dy1seg + (SPLIT ? (size_t)gp0 * a.seg_entries * 64 : 0), row0, a.code_rep,
+                             a.seg_s, a.seg_entries, tile, ntiles);
 #pragma unroll
-  for (int ps = 0; ps < 2; ++ps) {
-    const int64_t g0 = (int64_t)ps * a.mpad + row0;
+  for (int ps = 0; ps < NP; ++ps) {
+    const int64_t g0 = (int64_t)(gp0 + ps) * a.mpad + row0;
     store_tile<1, 64>(a.dy1 + g0 * 64, 64, B2 + ps * R * 68, 68);
     store_tile<1, 128>(a.dy2 + g0 * 128, 128, B1 + ps * R * 132, 132);
     store_tile<1, 256>(a.dy3 + g0 * 256, 256, XC + ps * R * 260, 260);
@@ -896,7 +934,7 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseB
   __syncthreads();
   store_tile<1, 64>(a.dy2 + row0 * 64, 64, B2, 68);
   store_tile<1, 128>(a.dy1 + row0 * 128, 128, H1, 132);
-  store_segment_sums<128, 1>(H1, 132, a.dy1seg, row0, a.code_rep, a.seg_s, a.seg_entries);
+  store_segment_sums<128, 1>(H1, 132, a.dy1seg, row0, a.code_rep, a.seg_s, a.seg_entries, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Adam state word: {int32 step, float lr/(1-b1^t), float sqrt(1-b2^t), pad}.  One thread
@@ -938,6 +976,7 @@ struct WgradJob {
   // fake pass together -- so the job runs over rows = ntiles*seg_s entries instead of all M rows;
   // entry e = tile*seg_s + s pairs with code row (16*tile)/seg_k + s.  rows == 0: plain job.
   int rows, seg_s, seg_k;
+  int seg_wrap;        // entries per pass when real and fake segment sums are kept apart (0: one set)
 };
 constexpr int kMaxJobs = 28;
 struct WgradArgs {
@@ -1010,14 +1049,15 @@ __device__ __forceinline__ void wgrad_block(const WgradJob& jb, int rbeg, int re
     int brow = row;
     if (seg_b) {
       // entry -> (tile, s) -> code row (16*tile)/K + s; exact divisions by reciprocal + fix-up
-      int tile = (int)((float)row * s_inv);
-      tile = tile * jb.seg_s > row ? tile - 1 : tile;
-      tile = (tile + 1) * jb.seg_s <= row ? tile + 1 : tile;
+      const int e = (jb.seg_wrap != 0 && row >= jb.seg_wrap) ? row - jb.seg_wrap : row;
+      int tile = (int)((float)e * s_inv);
+      tile = tile * jb.seg_s > e ? tile - 1 : tile;
+      tile = (tile + 1) * jb.seg_s <= e ? tile + 1 : tile;
       const int x = 16 * tile;
       int f0 = (int)((float)x * b_inv);
       f0 = f0 * jb.seg_k > x ? f0 - 1 : f0;
       f0 = (f0 + 1) * jb.seg_k <= x ? f0 + 1 : f0;
-      brow = f0 + (row - tile * jb.seg_s);
+      brow = f0 + (e - tile * jb.seg_s);
     } else if (!plain_b) {
       const int x = row >= jb.b_rowmod ? row - jb.b_rowmod : row;
       int qd = (int)((float)x * b_inv);
