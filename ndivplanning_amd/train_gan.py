@@ -21,7 +21,10 @@ What differs from the reference, on purpose:
 Extra YAML keys (all optional): `train_data_path: synthetic:<N>[:codes|images]` for seeded
 synthetic trajectories, `training.gan.noise_source`, `training.gan.use_graph`,
 `training.gan.steps_per_launch` (iterations per HIP-graph launch, default 4; the batches of one
-launch are staged into separate input slots, the arithmetic is unchanged).
+launch are staged into separate input slots, the arithmetic is unchanged),
+`training.gan.cache_codes` (default true: encode every trajectory once, the encoder being frozen).
+In data-parallel runs each rank caches only the trajectories of its own shard positions, so the
+cache fills over several epochs there.
 """
 import logging
 import os
@@ -93,6 +96,13 @@ def encode_batch(frames, encoder, seq_length):
     return torch.cat([cur, tgt], dim=2).reshape(b * (t - 1), -1).contiguous()
 
 
+def epoch_batches(n_items, batch_size, generator):
+    """Shuffled index batches of one epoch (ragged tail dropped): what DataLoader(shuffle=True,
+    drop_last=True) does, as an explicit list so that cached epochs can follow the same order."""
+    perm = torch.randperm(n_items, generator=generator)
+    return [perm[i:i + batch_size] for i in range(0, n_items - batch_size + 1, batch_size)]
+
+
 def train(config):
     g = config.training.gan
     random_seed = int(config.random_seed)
@@ -106,6 +116,7 @@ def train(config):
     noise_source = _get(g, "noise_source", "device")
     use_graph = bool(_get(g, "use_graph", True))
     steps_per_launch = int(_get(g, "steps_per_launch", 4))
+    cache_codes = bool(_get(g, "cache_codes", True))
 
     rank, world, local_rank = dp.env_world()
     if not torch.cuda.is_available():
@@ -131,9 +142,9 @@ def train(config):
             logging.info("visdom plotting disabled (%s)", e)
 
     dataset = make_dataset(config)
-    loader = data.DataLoader(dataset, batch_size=batch_size, shuffle=True, drop_last=True,
-                             generator=torch.Generator().manual_seed(random_seed))
-    if len(loader) == 0:
+    order_gen = torch.Generator().manual_seed(random_seed)
+    n_batches = len(dataset) // batch_size
+    if n_batches == 0:
         raise ValueError("dataset of %d trajectories is smaller than one batch of %d" % (len(dataset), batch_size))
     seq_length = int(dataset.seq_length)
     image_mode = getattr(dataset, "mode", "images") == "images"
@@ -152,11 +163,22 @@ def train(config):
                          use_graph=use_graph, noise_seed=random_seed * 1000 + rank,
                          steps_per_launch=steps_per_launch if (world == 1 and use_graph) else 1)
     group = trainer.nslots
+    # The encoder is frozen (train_gan.py:75-76, .detach() at 152-153), so a frame's code never
+    # changes: with `cache_codes` every trajectory is encoded (and its actions uploaded) once, in
+    # the first epoch that meets it; later epochs gather codes and actions on the device and touch
+    # neither the images nor the host.
+    code_cache = action_cache = cached = None
+    if cache_codes:
+        code_cache = torch.zeros(len(dataset), seq_length, 128, device=device)
+        action_cache = torch.zeros(len(dataset), seq_length, 4, device=device)
+        cached = torch.zeros(len(dataset), dtype=torch.bool)
     history = []
     for epoch in range(num_epochs):
         discriminator.train()
         decoder.train()
         pending = []                         # up to `group` prepared batches -> one graph launch
+        batches = epoch_batches(len(dataset), batch_size, order_gen)
+        lo, hi = dp.shard_bounds(batch_size, rank, world)
 
         def flush():
             if len(pending) == group and group > 1:
@@ -167,12 +189,28 @@ def train(config):
                     trainer.step(c_, a_, n_)
             del pending[:]
 
-        for inputs in loader:
-            frames, _states, actions, _goal = inputs
-            lo, hi = dp.shard_bounds(batch_size, rank, world)
-            frames = frames[lo:hi].float().to(device, non_blocking=True)
-            actions = actions[lo:hi].float().to(device, non_blocking=True)
-            codes = encode_batch(frames, encoder, seq_length)
+        all_cached = cached is not None and bool(cached.all())
+        loader = None if all_cached else iter(data.DataLoader(dataset, batch_sampler=[b.tolist() for b in batches]))
+        for idx in batches:
+            if all_cached:
+                mine = idx[lo:hi].to(device)
+                per_frame, actions = code_cache[mine], action_cache[mine]
+            else:
+                frames, _states, actions, _goal = next(loader)
+                frames = frames[lo:hi].float().to(device, non_blocking=True)
+                actions = actions[lo:hi].float().to(device, non_blocking=True)
+                if frames.dim() == 5:
+                    with torch.no_grad():
+                        b_, t_ = frames.shape[0], frames.shape[1]
+                        per_frame = encoder(frames.reshape((b_ * t_,) + tuple(frames.shape[2:]))).reshape(b_, t_, -1)
+                else:
+                    per_frame = frames
+                if cached is not None:
+                    mine = idx[lo:hi]
+                    code_cache[mine.to(device)] = per_frame
+                    action_cache[mine.to(device)] = actions
+                    cached[mine] = True
+            codes = encode_batch(per_frame, None, seq_length)
             acts = actions[:, :-1].reshape(-1, actions.size(-1))                # train_gan.py:137
             noise = None
             if noise_source == "cpu":                                           # train_gan.py:44
@@ -182,7 +220,7 @@ def train(config):
                 flush()
         flush()
         sums = dp.reduce_loss_shares(trainer.pop_loss_sums(), device=device)
-        d_avg, g_avg, div_avg = (v / len(loader) for v in sums)                 # train_gan.py:209-211
+        d_avg, g_avg, div_avg = (v / n_batches for v in sums)                   # train_gan.py:209-211
         history.append((d_avg, g_avg, div_avg))
         if rank == 0:
             logging.info("{}, D: {:4f}, G: {:4f}, div: {:4f}".format(epoch, d_avg, g_avg, div_avg))

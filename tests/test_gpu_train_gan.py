@@ -29,13 +29,13 @@ def _config(tmp_path, n_traj, mode, batch, k=6, epochs=1, dsteps=1, noise_source
 def _oracle_epoch(cfg):
     """Replay of train() on the CPU with the oracle: same RNG order (seed -> Decoder ->
     Discriminator -> per-step uniform_ noise), same seeded loader."""
-    from ndivplanning_amd.train_gan import encode_batch, make_dataset
+    from ndivplanning_amd.train_gan import encode_batch, epoch_batches, make_dataset
     g_cfg = cfg.training.gan
     torch.manual_seed(cfg.random_seed)
     g, d = O.init_params(cfg.random_seed, g_cfg.noise_dim)        # seeds and constructs in the reference order
     ds = make_dataset(cfg)
-    loader = torch.utils.data.DataLoader(ds, batch_size=g_cfg.batch_size, shuffle=True, drop_last=True,
-                                         generator=torch.Generator().manual_seed(cfg.random_seed))
+    batches = epoch_batches(len(ds), g_cfg.batch_size, torch.Generator().manual_seed(cfg.random_seed))
+    loader = torch.utils.data.DataLoader(ds, batch_sampler=[b.tolist() for b in batches])
     sm = O.StepMath(g, d, lr=g_cfg.learning_rate, pairwise_div_factor=g_cfg.pairwise_div_factor)
     sums = [0.0, 0.0, 0.0]
     for frames, _s, actions, _g in loader:
@@ -76,12 +76,23 @@ def test_checkpoints_are_reference_style_whole_modules(tmp_path):
     assert dis(a.detach(), z[:, :256].contiguous()).shape == (12, 1)
 
 
-def test_image_mode_runs(tmp_path):
+def test_image_mode_runs_and_code_cache_is_exact(tmp_path):
+    """Image mode end to end (MIOpen encoder -> HIP step), and the frozen-encoder code cache:
+    epochs served from the cache must reproduce the run that re-encodes every batch."""
     from ndivplanning_amd.train_gan import train
-    cfg = _config(tmp_path, 4, "images", 2, k=3, noise_source="device")
-    hist = train(cfg)
-    assert all(torch.isfinite(torch.tensor(h)).all() for h in hist)
-    assert 1.0 < hist[0][0] < 2.0 and 0.3 < hist[0][1] < 1.2            # ~2 ln 2 and ~ln 2 at initialisation
+    hists = []
+    for cache in (True, False):
+        cfg = _config(tmp_path, 4, "images", 2, k=3, epochs=3, noise_source="cpu", stage=100)
+        cfg.training.gan.cache_codes = cache
+        hists.append(train(cfg))
+    assert all(torch.isfinite(torch.tensor(h)).all() for h in hists[0])
+    assert 1.0 < hists[0][0][0] < 2.0 and 0.3 < hists[0][0][1] < 1.2    # ~2 ln 2 and ~ln 2 at initialisation
+    for a, b in zip(hists[0], hists[1]):                                 # cached epochs 2, 3 vs re-encoded
+        assert abs(a[0] - b[0]) <= 1e-5 and abs(a[1] - b[1]) <= 1e-5
+        # NDiv at FLAT = 14 amplifies the last-bit differences of MIOpen's conv results (which are
+        # not even run-to-run identical; tests/test_oracle_golden.py::test_manual_step_teacher_forced
+        # explains the amplification); only sanity here
+        assert a[2] > 0 and b[2] > 0
 
 
 def _rank_main(rank, world, port, cfg_dict, out_dir):
