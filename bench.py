@@ -120,6 +120,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("NDP_BENCH_ONE_GPU") == "1":
+        # rehearsal of the N > 1 path on a one-GPU box: all ranks share cuda:0 (needs NDP_DIST_BACKEND=gloo,
+        # RCCL refuses two ranks on one device); the number it prints is not a measurement
+        local_rank = 0
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs a torch.distributed.run launch with that many ranks" % args.gpus)
@@ -129,10 +133,15 @@ def main():
 
     import torch.distributed as dist
     from ndivplanning_amd import dp
-    reduce_fn = None
+    reduce_fn, p2p, exchange = None, None, "none"
     if world > 1 or args.force_dp:
         dp.init_process_group(dev, force=args.force_dp)     # RCCL; keeps its banner off stdout
-        reduce_fn = dp.sum_all_reduce()
+        # gradient exchange: in-kernel peer-to-peer (hipIpc over xGMI) if it passes its self-check on
+        # this node, RCCL all-reduce between the phases otherwise (NDP_DP_EXCHANGE=rccl|p2p forces one)
+        if world > 1:
+            p2p, reduce_fn, exchange = dp.make_exchange(dev, world, log=lambda m_: print("[bench] " + m_, file=sys.stderr))
+        else:
+            reduce_fn, exchange = dp.sum_all_reduce(), "rccl"
 
     from ndivplanning_amd import _capi
     from ndivplanning_amd.models.gan import Decoder, Discriminator
@@ -149,8 +158,13 @@ def main():
     dec, dis = dec.to(dev), dis.to(dev)
     codes, actions, noise = O.synthetic_batch(1000 + rank, batch, k, nz, steps=1)
     spl = args.steps_per_launch if (reduce_fn is None and not args.no_graph) else 1
-    tr = GanTrainer(dec, dis, flat=flat, num_sample=k, flat_global=flat * world, reduce_fn=reduce_fn,
-                    use_graph=not args.no_graph, noise_seed=rank, steps_per_launch=spl)
+
+    def make_trainer():
+        dec.load_state_dict(g)
+        dis.load_state_dict(d)
+        return GanTrainer(dec, dis, flat=flat, num_sample=k, flat_global=flat * world, reduce_fn=reduce_fn, p2p=p2p,
+                          use_graph=not args.no_graph, noise_seed=rank, steps_per_launch=spl)
+    tr = make_trainer()
 
     # step-0 parity figure (outside the timed region): NDiv / losses vs the oracle on rank 0's shard
     parity = None
@@ -162,14 +176,16 @@ def main():
         parity = {"ndiv_rel_err": abs(pd - out["pair_div"].item()) / max(1.0, abs(out["pair_div"].item())),
                   "d_loss_abs_err": abs(dl - out["d_loss"].item()), "g_loss_abs_err": abs(gl - out["g_loss"].item()),
                   "action_hat_max_abs_err": (tr.action_hat[:m].cpu() - out["action_hat"]).abs().max().item()}
-    else:
+
+    def fill_slots():
+        # every input slot holds its own resident synthetic batch
         tr.codes.copy_(codes)
         tr.actions.copy_(actions)
-    # every input slot holds its own resident synthetic batch
-    for slot in range(1, spl):
-        c_, a_, _ = O.synthetic_batch(2000 + 17 * slot + rank, batch, k, nz, steps=1)
-        tr.codes_slots[slot].copy_(c_)
-        tr.actions_slots[slot].copy_(a_)
+        for slot in range(1, spl):
+            c_, a_, _ = O.synthetic_batch(2000 + 17 * slot + rank, batch, k, nz, steps=1)
+            tr.codes_slots[slot].copy_(c_)
+            tr.actions_slots[slot].copy_(a_)
+    fill_slots()
 
     def run_steps(n):
         done = 0
@@ -184,7 +200,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    barrier()
     run_steps(args.warmup)
+    if p2p is not None:
+        # a wait that timed out during warm-up (status word) means the exchange does not work on this
+        # node although its self-check passed: fall back to the RCCL path rather than time garbage
+        bad = torch.tensor([p2p.status()], dtype=torch.int32, device=dev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()) != 0:
+            print("[bench] peer-to-peer exchange timed out in warm-up; falling back to RCCL", file=sys.stderr)
+            del tr
+            p2p.close()
+            p2p, reduce_fn, exchange, spl = None, dp.sum_all_reduce(), "rccl (p2p timed out in warm-up)", 1
+            tr = make_trainer()
+            fill_slots()
+            barrier()
+            run_steps(args.warmup)
     run_steps(spl + 1)                 # make sure both graphs exist before timing
     barrier()
     t0 = time.perf_counter()
@@ -196,26 +227,42 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     losses = tr.losses()
+    hip_graph = bool(tr.use_graph)
 
     # per-kernel durations: HIP events around every launch, eager launches of the same step
+    # (every rank steps -- the exchange needs all of them -- rank 0 records)
     kernels = {}
+    saved = tr.use_graph
+    tr.use_graph = False
     if rank == 0:
-        saved = tr.use_graph
-        tr.use_graph = False
         _capi.timing_enable(True)
-        reps = 50
-        for _ in range(reps):
-            tr.step()
-        torch.cuda.synchronize(dev)
+    reps = 50
+    for _ in range(reps):
+        tr.step()
+    torch.cuda.synchronize(dev)
+    if rank == 0:
         timed = _capi.timing_collect()
         _capi.timing_enable(False)
-        tr.use_graph = saved
         for name, (ms, cnt) in timed.items():
             us = 1e3 * ms / max(cnt, 1)
             macs = KERNEL_MACS_PER_ROW.get(name)
             kernels[name] = {"avg_us": round(us, 3), "launches_per_step": cnt / reps,
                              "tflops": round(2.0 * macs * m / (us * 1e-6) / 1e12, 3) if macs else None}
+    tr.use_graph = saved
 
+    replicas_identical = None
+    if world > 1:
+        # the replicas must have stayed bit-identical: compare a checksum of the parameter bits
+        bits = torch.cat([tr.g_flat.detach(), tr.d_flat.detach()]).view(torch.int32).to(torch.int64)
+        mine = torch.stack([bits.sum(), (bits * torch.arange(1, bits.numel() + 1, device=dev)).sum()])
+        lo_, hi_ = mine.clone(), mine.clone()
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(torch.equal(lo_, hi_))
+        if p2p is not None:
+            p2p.check()                # raises if any wait timed out
+            del tr
+            p2p.close()
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -235,7 +282,8 @@ def main():
                                "batch=%d trajectories per GPU, traj_len=8, num_sample=%d, noise_dim=2" % (batch, k),
                    "rows_per_gpu": m, "global_batch": batch * world, "parallelism": "dp%d" % world,
                    "trajectories_per_sec": round(iters_per_s * batch * world, 1),
-                   "hip_graph": bool(tr.use_graph), "steps_per_graph_launch": spl if tr.use_graph else 0, "last_losses": {"D": losses[0], "G": losses[1], "ndiv": losses[2]}},
+                   "hip_graph": hip_graph, "steps_per_graph_launch": spl if hip_graph else 0,
+                   "gradient_exchange": exchange, "replicas_bit_identical": replicas_identical, "last_losses": {"D": losses[0], "G": losses[1], "ndiv": losses[2]}},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                      "traffic": PMC_HBM_BYTES_DEFAULT.get(dom) if (batch, k) == (64, 6) else None,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NDP_VERSION 100          /* 0.1.0 */
+#define NDP_VERSION 110          /* 0.1.1: ndp_p2p_*, ndp_step_config.p2p */
 
 #define NDP_OK            0
 #define NDP_E_ARG         1      /* bad argument (shape, alignment, null) */
@@ -160,6 +160,7 @@ int ndp_adam_step(float *params, const float *grad, float *exp_avg, float *exp_a
  * the GLOBAL row count, so inv_m_global = 1/(M summed over ranks); the NDiv term
  * is a sum and is not scaled.  Gradients of all ranks are then SUMMED.
  */
+struct ndp_p2p;
 typedef struct ndp_step_config {
   int32_t noise_dim;           /* training.gan.noise_dim  (1..16) */
   int32_t num_sample;          /* training.gan.num_sample (1..256) */
@@ -170,6 +171,10 @@ typedef struct ndp_step_config {
   int32_t fuse_adam;           /* 1: apply Adam inside the phase; 0: leave grads */
   int32_t device_noise;        /* 1: G forward draws the noise itself (see `noise` below) */
   uint64_t noise_seed;         /* stream id of the device noise (e.g. the rank) */
+  const struct ndp_p2p *p2p;   /* NULL, or the peer-to-peer gradient exchange (see below): the
+                                * kernel that sums the split-K slabs then also SUMS the gradient
+                                * over ranks before Adam, so a data-parallel step has the same
+                                * launches as a single-GPU step and is graph-capturable */
 } ndp_step_config;
 
 /* Caller-owned persistent state of one trainer (all device memory). */
@@ -216,6 +221,56 @@ int ndp_step_apply_adam(const ndp_step_config *cfg, const ndp_step_buffers *buf,
  * Philox-4x32-10 keyed by seed, counter (i/4, *offset_dev), word i%4. */
 int ndp_uniform_noise(float *out, int64_t n, uint64_t seed, const int32_t *offset_dev,
                       void *stream);
+
+/* ------------------------------------------- peer-to-peer gradient exchange ---
+ * The data-parallel exchange of SURVEY.md section 8e (two flat SUM all-reduces
+ * per step: 58,305 and 83,780 floats) without a collective library: the
+ * reference has no collectives (single process, train_gan.py:115-207); this is
+ * what replaces "one optimizer sees the whole batch" when the batch is sharded
+ * over one process per GPU.
+ *
+ * Every rank owns one REGION of device memory (uncached / fine-grained, so that
+ * stores arriving over xGMI and the polling loads bypass the caches), exported
+ * with hipIpc and mapped by every peer.  One exchange, inside the kernel that
+ * has just summed the rank's split-K slabs:
+ *   push   each workgroup stores its 256 gradient values into the inbox slot
+ *          [src = this rank][step parity] of EVERY peer's region, fences at
+ *          system scope, then releases flag[src][workgroup] = step there;
+ *   wait   it polls the flags the peers set in its OWN region (bounded by
+ *          timeout_ms: on expiry the region's status word is set, the wait is
+ *          skipped from then on and ndp_p2p_status reports it -- never a hang);
+ *   sum    own value + the peers' values from its own inbox in rank order
+ *          0..world-1: every rank computes bit-identical sums, so the replicas
+ *          stay bit-identical, run after run.
+ * Inboxes are double-buffered on the step's parity: a peer can be at most one
+ * exchange ahead (it needs this rank's next push to go further), so no second
+ * barrier is needed.  `step` is the network's Adam step count (state word [0]),
+ * which must advance by one per exchange and be the same on all ranks.
+ * These are the only functions of the library that allocate or synchronise. */
+#define NDP_P2P_MAX_RANKS    8
+#define NDP_P2P_HANDLE_BYTES 64          /* sizeof(hipIpcMemHandle_t) */
+
+typedef struct ndp_p2p {
+  int32_t world, rank;
+  int32_t timeout_ms;                    /* bound of one wait (0 = 10,000) */
+  int32_t reserved;
+  void   *region[NDP_P2P_MAX_RANKS];     /* region[rank] = own allocation, others = mapped peers */
+} ndp_p2p;
+
+int64_t ndp_p2p_region_bytes(void);
+int ndp_p2p_region_alloc(void **region);                 /* zero-filled; synchronises */
+int ndp_p2p_region_free(void *region);
+int ndp_p2p_region_reset(void *region);                  /* zero flags + status; synchronises */
+int ndp_p2p_export(void *region, void *handle_out);      /* NDP_P2P_HANDLE_BYTES bytes, host memory */
+int ndp_p2p_open(const void *handle, void **mapped_out); /* a PEER process's handle */
+int ndp_p2p_close(void *mapped);
+/* status word of the own region: 0 = ok, 1 + r = a wait for rank r timed out (HOST int out) */
+int ndp_p2p_status(const ndp_p2p *p2p, int32_t *status_out);
+/* The exchange alone: out[i] = sum over ranks of in[i] (n <= the capacity of `net`'s inbox:
+ * ndp_d_param_count() for net 0, ndp_g_param_count(NDP_MAX_NOISE_DIM) for net 1).  step_word:
+ * device int32, same value on every rank, larger than at the previous exchange on this net. */
+int ndp_p2p_all_reduce(const ndp_p2p *p2p, int net, const float *in, float *out, int64_t n,
+                       const int32_t *step_word, void *stream);
 
 /* ------------------------------------------------------------ measurement ---
  * Per-kernel timing for bench.py: while enabled (per host thread) every kernel

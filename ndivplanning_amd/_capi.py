@@ -25,12 +25,23 @@ class NdpError(RuntimeError):
     pass
 
 
+P2P_MAX_RANKS = 8
+P2P_HANDLE_BYTES = 64
+
+
+class P2P(Structure):
+    """struct ndp_p2p (include/ndp.h)."""
+    _fields_ = [("world", c_int32), ("rank", c_int32), ("timeout_ms", c_int32), ("reserved", c_int32),
+                ("region", c_void_p * P2P_MAX_RANKS)]
+
+
 class StepConfig(Structure):
     """struct ndp_step_config (include/ndp.h)."""
     _fields_ = [("noise_dim", c_int32), ("num_sample", c_int32), ("flat", c_int64),
                 ("inv_m_global", c_float), ("pairwise_div_factor", c_float),
                 ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
-                ("fuse_adam", c_int32), ("device_noise", c_int32), ("noise_seed", c_uint64)]
+                ("fuse_adam", c_int32), ("device_noise", c_int32), ("noise_seed", c_uint64),
+                ("p2p", POINTER(P2P))]
 
 
 class StepBuffers(Structure):
@@ -71,6 +82,15 @@ SIGNATURES = {
     "ndp_step_pack_params": (c_int, [POINTER(StepConfig), POINTER(StepBuffers), c_void_p]),
     "ndp_step_apply_adam": (c_int, [POINTER(StepConfig), POINTER(StepBuffers), c_int, c_void_p]),
     "ndp_uniform_noise": (c_int, [c_void_p, c_int64, c_uint64, c_void_p, c_void_p]),
+    "ndp_p2p_region_bytes": (c_int64, []),
+    "ndp_p2p_region_alloc": (c_int, [POINTER(c_void_p)]),
+    "ndp_p2p_region_free": (c_int, [c_void_p]),
+    "ndp_p2p_region_reset": (c_int, [c_void_p]),
+    "ndp_p2p_export": (c_int, [c_void_p, c_void_p]),
+    "ndp_p2p_open": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "ndp_p2p_close": (c_int, [c_void_p]),
+    "ndp_p2p_status": (c_int, [POINTER(P2P), POINTER(c_int32)]),
+    "ndp_p2p_all_reduce": (c_int, [POINTER(P2P), c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "ndp_timing_enable": (c_int, [c_int]),
     "ndp_timing_collect": (c_int, [ctypes.c_char_p, c_int, POINTER(c_float), POINTER(c_int32), c_int]),
 }

@@ -1207,8 +1207,75 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
 struct LossTerm {
   const float* partials; int count; float scale; int slot;   // losses[slot] = scale * sum
 };
+// Peer-to-peer SUM over ranks (include/ndp.h, "peer-to-peer gradient exchange"). Region layout in
+// 4-byte words: status[64] | flags[net 2][src 8][workgroup kP2PBlocks] | inbox D [src 8][parity 2][kP2PCapD]
+// | inbox G [src 8][parity 2][kP2PCapG].
+constexpr int kP2PRanks = 8;
+constexpr int kP2PCapD = 58368;                 // >= 58,305, multiple of kThreads
+constexpr int kP2PCapG = 86016;                 // >= Decoder(16) = 85,572
+constexpr int kP2PBlocks = kP2PCapG / kThreads; // 336 workgroups at most
+constexpr int64_t kP2PFlagOff = 64;
+constexpr int64_t kP2PInboxD = kP2PFlagOff + 2ll * kP2PRanks * kP2PBlocks;
+constexpr int64_t kP2PInboxG = kP2PInboxD + (int64_t)kP2PRanks * 2 * kP2PCapD;
+constexpr int64_t kP2PWords = kP2PInboxG + (int64_t)kP2PRanks * 2 * kP2PCapG;
+
+struct P2PArgs {
+  int world, rank, net;                 // world <= 1: no exchange
+  long long timeout_ticks;              // wall_clock64 ticks (100 MHz)
+  uint32_t* region[kP2PRanks];
+};
+
+// one value per thread; every thread of the workgroup must call (barriers inside)
+__device__ __forceinline__ float p2p_sum(const P2PArgs& x, float g, int64_t p, bool valid, uint32_t step) {
+  const int W = x.world, me = x.rank;
+  const int64_t cap = x.net == 0 ? kP2PCapD : kP2PCapG;
+  const int64_t inbox = x.net == 0 ? kP2PInboxD : kP2PInboxG;
+  const int64_t par = (int64_t)(step & 1u) * cap;
+  if (valid) {
+    const int64_t at = inbox + (int64_t)me * 2 * cap + par + p;
+#pragma unroll
+    for (int r = 0; r < kP2PRanks; ++r)
+      if (r < W && r != me)
+        __hip_atomic_store(reinterpret_cast<float*>(x.region[r]) + at, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __threadfence_system();               // this thread's pushes are visible system-wide ...
+  __syncthreads();                      // ... and so are the whole workgroup's, before any flag goes out
+  const int t = threadIdx.x;
+  if (t < W && t != me) {
+    const int64_t fbase = kP2PFlagOff + (int64_t)x.net * kP2PRanks * kP2PBlocks + blockIdx.x;
+    __hip_atomic_store(x.region[t] + fbase + (int64_t)me * kP2PBlocks, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    uint32_t* status = x.region[me];
+    const uint32_t* flag = x.region[me] + fbase + (int64_t)t * kP2PBlocks;
+    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) {
+      const long long t0 = wall_clock64();
+      while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - step) < 0) {
+        if (wall_clock64() - t0 > x.timeout_ticks) {     // exit condition every wave reaches
+          __hip_atomic_store(status, (uint32_t)(1 + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+  }
+  __syncthreads();
+  __threadfence_system();               // acquire side for the threads that did not poll
+  float v[kP2PRanks];
+#pragma unroll
+  for (int r = 0; r < kP2PRanks; ++r)
+    v[r] = (valid && r < W && r != me)
+               ? __hip_atomic_load(reinterpret_cast<const float*>(x.region[me]) + inbox + (int64_t)r * 2 * cap + par + p,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+               : 0.f;
+  float s = 0.f;                        // rank order 0..W-1 on every rank: bit-identical replicas
+#pragma unroll
+  for (int r = 0; r < kP2PRanks; ++r)
+    if (r < W) s += (r == me) ? g : v[r];
+  return s;
+}
+
 struct ReduceArgs {
   const float* slabs; int nchunks; int64_t slab_stride; int64_t n;
+  P2PArgs p2p;
   float* grad;                         // [n] or null
   float *params, *exp_avg, *exp_avg_sq;   // Adam (params null -> no update)
   const int32_t* step;                 // Adam state word (already advanced for this step)
@@ -1229,11 +1296,11 @@ __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& 
 __global__ __launch_bounds__(kThreads) void k_reduce_adam(ReduceArgs a) {
   __shared__ float sh[8];
   const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  float g = 0.f;
   if (p < a.n) {
     // fixed summation order (bitwise reproducible); 16 loads are issued before the first add so
     // that a slab sum costs ~2 memory round trips instead of nchunks/4
     const float* sp = a.slabs + p;
-    float g = 0.f;
     int ch = 0;
     for (; ch + 16 <= a.nchunks; ch += 16) {
       float t[16];
@@ -1249,6 +1316,9 @@ __global__ __launch_bounds__(kThreads) void k_reduce_adam(ReduceArgs a) {
 #pragma unroll
       for (int u = 0; u < 16; ++u) g += t[u];
     }
+  }
+  if (a.p2p.world > 1) g = p2p_sum(a.p2p, g, p, p < a.n, (uint32_t)a.step[0]);   // uniform branch
+  if (p < a.n) {
     if (a.grad != nullptr) a.grad[p] = g;
     if (a.params != nullptr) {
       const float step_size = reinterpret_cast<const float*>(a.step)[1];

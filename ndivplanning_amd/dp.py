@@ -65,7 +65,9 @@ def init_process_group(device=None, force=False):
                 dist.all_reduce(warm)                       # creates the communicator (and the banner) now
                 torch.cuda.synchronize(torch.device(device))
         else:
-            dist.init_process_group(backend=backend, **kw)
+            with _stdout_to_stderr():                       # gloo reports its connections on stdout too
+                dist.init_process_group(backend=backend, **kw)
+                dist.barrier()
     return rank, world
 
 
@@ -105,3 +107,165 @@ def reduce_loss_shares(shares, device=None):
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.tolist()
+
+
+class P2PExchange:
+    """The in-kernel gradient exchange of include/ndp.h ("peer-to-peer gradient exchange"): one
+    uncached region per rank, mapped into every peer with hipIpc; the step's slab-reduce kernels
+    then sum the gradients over ranks themselves, so a data-parallel step has the launches of a
+    single-GPU step and replays as one HIP graph.  One process per GPU of ONE node (xGMI or, in
+    tests, several processes sharing a GPU).  Needs an initialised torch.distributed group for
+    the handle exchange only.  `GanTrainer(p2p=...)` takes the object."""
+
+    def __init__(self, device, group=None, timeout_ms=10000):
+        from . import _capi
+        self._capi = _capi
+        self.lib = _capi.load()
+        self.device = torch.device(device)
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if not 1 <= self.world <= _capi.P2P_MAX_RANKS:
+            raise ValueError("peer-to-peer exchange supports up to %d ranks, got %d" % (_capi.P2P_MAX_RANKS, self.world))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import ctypes
+        self._mapped = []
+        self._region = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _capi.check(self.lib.ndp_p2p_region_alloc(ctypes.byref(self._region)), "ndp_p2p_region_alloc")
+            handle = ctypes.create_string_buffer(_capi.P2P_HANDLE_BYTES)
+            _capi.check(self.lib.ndp_p2p_export(self._region, handle), "ndp_p2p_export")
+            handles = [None] * self.world
+            dist.all_gather_object(handles, (self.rank, os.getpid(), handle.raw), group=group)
+            self.struct = _capi.P2P()
+            self.struct.world, self.struct.rank, self.struct.timeout_ms = self.world, self.rank, int(timeout_ms)
+            for r, (src, pid, raw) in enumerate(handles):
+                if src != r:
+                    raise RuntimeError("peer-to-peer exchange: handle list out of rank order")
+                if r == self.rank:
+                    self.struct.region[r] = self._region.value
+                    continue
+                if pid == os.getpid():
+                    raise RuntimeError("peer-to-peer exchange needs one PROCESS per rank (hipIpc)")
+                mapped = ctypes.c_void_p()
+                _capi.check(self.lib.ndp_p2p_open(ctypes.create_string_buffer(raw, len(raw)), ctypes.byref(mapped)),
+                            "ndp_p2p_open(rank %d)" % r)
+                self._mapped.append(mapped)
+                self.struct.region[r] = mapped.value
+        self._barrier()
+
+    # ---- helpers
+    def _barrier(self):
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=self.group)
+
+    def pointer(self):
+        import ctypes
+        return ctypes.pointer(self.struct)
+
+    def status(self):
+        """0 = ok; 1 + r = a wait for rank r's push timed out (results since then are garbage)."""
+        import ctypes
+        out = ctypes.c_int32(-1)
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)
+            self._capi.check(self.lib.ndp_p2p_status(self.pointer(), ctypes.byref(out)), "ndp_p2p_status")
+        return int(out.value)
+
+    def check(self):
+        st = self.status()
+        if st != 0:
+            raise RuntimeError("peer-to-peer gradient exchange: rank %d timed out waiting for rank %d"
+                               % (self.rank, st - 1))
+
+    def reset(self):
+        """Zero flags and status (collective: no exchange may be in flight on any rank)."""
+        self._barrier()
+        with torch.cuda.device(self.device):
+            self._capi.check(self.lib.ndp_p2p_region_reset(self._region), "ndp_p2p_region_reset")
+        self._barrier()
+
+    def all_reduce(self, x, step_word, net=0, out=None):
+        """out = sum over ranks of x (flat fp32 CUDA tensor); step_word: int32 CUDA tensor whose
+        [0] is this exchange's number (same on all ranks, increasing per net)."""
+        c = self._capi
+        c.require_gpu_f32(x, "x")
+        out = torch.empty_like(x) if out is None else out
+        c.check(self.lib.ndp_p2p_all_reduce(self.pointer(), int(net), c.ptr(x), c.ptr(out), x.numel(), c.ptr(step_word),
+                                            c.stream_ptr()), "ndp_p2p_all_reduce")
+        return out
+
+    def self_check(self, trials=6):
+        """Exchange integer-valued vectors (their sums are exact in any order) on both nets and
+        compare with torch.distributed's all-reduce.  Collective; True on EVERY rank only if all
+        ranks saw exact results and no timeout.  Leaves the region reset."""
+        ok = True
+        try:
+            with torch.cuda.device(self.device):
+                word = torch.zeros(4, dtype=torch.int32, device=self.device)
+                for net, n in ((0, 58305), (1, 83780)):
+                    for trial in range(1, trials + 1):
+                        gen = torch.Generator().manual_seed(1000 * trial + 10 * self.rank + net)
+                        x = torch.randint(-4096, 4096, (n,), generator=gen).float().to(self.device)
+                        word.fill_(trial)
+                        got = self.all_reduce(x, word, net=net)
+                        ref = x.clone()
+                        if dist.get_backend(self.group) == "nccl":
+                            dist.all_reduce(ref, group=self.group)
+                        else:
+                            ref_cpu = ref.cpu()
+                            dist.all_reduce(ref_cpu, group=self.group)
+                            ref = ref_cpu.to(self.device)
+                        ok = ok and bool(torch.equal(got, ref))
+                ok = ok and self.status() == 0
+        except Exception as exc:                             # noqa: BLE001 - any failure disables the path
+            import sys
+            print("ndivplanning_amd: peer-to-peer self-check raised %r" % (exc,), file=sys.stderr)
+            ok = False
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        if dist.get_backend(self.group) == "nccl":
+            flag = flag.to(self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        self.reset()
+        return bool(flag.item() == 1)
+
+    def close(self):
+        if self._region is None:
+            return
+        self._barrier()
+        with torch.cuda.device(self.device):
+            for m in self._mapped:
+                self.lib.ndp_p2p_close(m)
+            self._mapped = []
+            self._barrier()
+            self.lib.ndp_p2p_region_free(self._region)
+        self._region = None
+
+
+def make_exchange(device, world, log=None):
+    """Pick the gradient exchange of a data-parallel run: the in-kernel peer-to-peer exchange when
+    it passes its self-check on this node, torch.distributed's all-reduce (RCCL) otherwise.
+    NDP_DP_EXCHANGE=rccl|p2p forces one.  Returns (p2p_or_None, reduce_fn_or_None, name)."""
+    if world <= 1:
+        return None, None, "none"
+    want = os.environ.get("NDP_DP_EXCHANGE", "auto")
+    if want != "rccl" and world <= 8 and torch.device(device).type == "cuda":
+        p2p = None
+        try:
+            p2p = P2PExchange(device)
+            good = p2p.self_check()
+        except Exception as exc:                                 # noqa: BLE001
+            good = False
+            if log:
+                log("peer-to-peer exchange unavailable: %r" % (exc,))
+        # every rank must take the same branch: self_check already agreed; constructor failures are
+        # agreed on here
+        flag = torch.tensor([1 if good else 0], dtype=torch.int32,
+                            device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if flag.item() == 1:
+            return p2p, None, "p2p"
+        if want == "p2p":
+            raise RuntimeError("NDP_DP_EXCHANGE=p2p but the peer-to-peer exchange failed its self-check")
+        if log:
+            log("peer-to-peer exchange failed its self-check; using the RCCL all-reduce")
+    return None, sum_all_reduce(), "rccl"

@@ -157,11 +157,17 @@ def train(config):
     decoder, discriminator = decoder.to(device), discriminator.to(device)
 
     flat_local = local_batch * (seq_length - 1)
+    # gradient exchange of a data-parallel run: summed inside the slab-reduce kernels over hipIpc-mapped
+    # peer memory when that passes its self-check on this node (the step stays one graph), RCCL
+    # all-reduce between the phases otherwise
+    p2p, reduce_fn, exchange = dp.make_exchange(device, world, log=logging.info)
+    if world > 1 and rank == 0:
+        logging.info("data parallel over %d ranks, gradient exchange: %s", world, exchange)
     trainer = GanTrainer(decoder, discriminator, flat=flat_local, num_sample=num_sample, lr=lr_rate,
                          betas=(0.5, 0.999), pairwise_div_factor=float(div_factor), discrim_steps=dsteps,
-                         flat_global=flat_local * world, reduce_fn=dp.sum_all_reduce() if world > 1 else None,
+                         flat_global=flat_local * world, reduce_fn=reduce_fn, p2p=p2p,
                          use_graph=use_graph, noise_seed=random_seed * 1000 + rank,
-                         steps_per_launch=steps_per_launch if (world == 1 and use_graph) else 1)
+                         steps_per_launch=steps_per_launch if (reduce_fn is None and use_graph) else 1)
     group = trainer.nslots
     # The encoder is frozen (train_gan.py:75-76, .detach() at 152-153), so a frame's code never
     # changes: with `cache_codes` every trajectory is encoded (and its actions uploaded) once, in
@@ -219,6 +225,8 @@ def train(config):
             if len(pending) == group:
                 flush()
         flush()
+        if p2p is not None:
+            p2p.check()                      # a timed-out wait is an error, not a silent wrong sum
         sums = dp.reduce_loss_shares(trainer.pop_loss_sums(), device=device)
         d_avg, g_avg, div_avg = (v / n_batches for v in sums)                   # train_gan.py:209-211
         history.append((d_avg, g_avg, div_avg))
@@ -233,6 +241,9 @@ def train(config):
                 torch.cuda.synchronize(device)
                 torch.save(discriminator, os.path.join(config.gan_save_path, "gan_discriminator_{}.pt".format(epoch)))
                 torch.save(decoder, os.path.join(config.gan_save_path, "gan_decoder_{}.pt".format(epoch)))
+    if p2p is not None:
+        del trainer
+        p2p.close()
     return history
 
 

@@ -9,7 +9,9 @@ updated D, G loss, NDiv, backward through D and G, G Adam).  See include/ndp.h.
 Data parallelism: each rank holds `flat` of the
 `flat_global` rows.  BCE is a mean over the global row count (inv_m_global),
 NDiv is a sum, so per-rank gradients are SUMMED by `reduce_fn` (an all-reduce over
-RCCL), after which every rank applies the same Adam update to its replica.
+RCCL), after which every rank applies the same Adam update to its replica -- or, with
+`p2p` (dp.P2PExchange), summed inside the slab-reduce kernels over hipIpc-mapped peer memory, so
+the data-parallel step is the single-GPU step (fused Adam, one HIP graph).
 """
 import ctypes
 
@@ -23,7 +25,7 @@ class GanTrainer:
     def __init__(self, decoder: Decoder, discriminator: Discriminator, *, flat: int, num_sample: int,
                  lr: float = 2e-4, betas=(0.5, 0.999), eps: float = 1e-8, pairwise_div_factor: float = 0.1,
                  discrim_steps: int = 1, flat_global: int = None, reduce_fn=None, use_graph: bool = True,
-                 noise_seed: int = 0, steps_per_launch: int = 1):
+                 noise_seed: int = 0, steps_per_launch: int = 1, p2p=None):
         self.lib = _capi.load()
         self.decoder, self.discriminator = decoder, discriminator
         self.noise_dim = decoder.noise_dim
@@ -31,7 +33,12 @@ class GanTrainer:
         self.flat_global = int(flat_global) if flat_global is not None else self.flat
         self.m = self.flat * self.k
         self.discrim_steps = int(discrim_steps)
+        if p2p is not None and reduce_fn is not None:
+            raise ValueError("give either p2p (in-kernel exchange) or reduce_fn (collective between the phases)")
         self.reduce_fn = reduce_fn
+        # dp.P2PExchange: the slab-reduce kernels sum the gradients over ranks themselves, the step
+        # keeps the single-GPU launch sequence (fused Adam, one graph)
+        self.p2p = p2p
         # With a collective between the phases the step cannot be one graph, and replaying
         # three graph segments costs more (~8 us of launch gap each) than launching the 8 kernels
         # eagerly, whose host cost hides behind the GPU work (measured: 136 vs 156 us/step).
@@ -68,7 +75,8 @@ class GanTrainer:
             noise_dim=self.noise_dim, num_sample=self.k, flat=self.flat,
             inv_m_global=1.0 / float(self.flat_global * self.k), pairwise_div_factor=float(pairwise_div_factor),
             lr=float(lr), beta1=float(betas[0]), beta2=float(betas[1]), eps=float(eps),
-            fuse_adam=0 if reduce_fn is not None else 1, device_noise=0, noise_seed=self.noise_seed)
+            fuse_adam=0 if reduce_fn is not None else 1, device_noise=0, noise_seed=self.noise_seed,
+            p2p=p2p.pointer() if p2p is not None else None)
         nws = self.lib.ndp_step_workspace_floats(ctypes.byref(self.cfg))
         if nws <= 0:
             raise _capi.NdpError("bad step configuration (flat=%d, num_sample=%d)" % (self.flat, self.k))

@@ -95,10 +95,11 @@ def test_image_mode_runs_and_code_cache_is_exact(tmp_path):
         assert a[2] > 0 and b[2] > 0
 
 
-def _rank_main(rank, world, port, cfg_dict, out_dir):
+def _rank_main(rank, world, port, cfg_dict, out_dir, exchange):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0", NDP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      LOCAL_RANK="0", NDP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      NDP_DP_EXCHANGE=exchange)
     import torch.distributed as dist
     from ndivplanning_amd import train_gan
     from ndivplanning_amd.utils.file import AttrDict
@@ -112,23 +113,28 @@ def _rank_main(rank, world, port, cfg_dict, out_dir):
     train_gan.GanTrainer = spy
     hist = train_gan.train(cfg)
     t = captured["t"]
-    torch.save({"g": t.g_flat.cpu(), "d": t.d_flat.cpu(), "hist": hist}, os.path.join(out_dir, "rank%d.pt" % rank))
+    torch.save({"g": t.g_flat.cpu(), "d": t.d_flat.cpu(), "hist": hist, "p2p": t.p2p is not None,
+                "graph": bool(t.use_graph)}, os.path.join(out_dir, "rank%d.pt" % rank))
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_equal_single_process(tmp_path):
-    """2 processes (gloo, both on cuda:0) each training half of every global batch of 8 vs one
-    process training the whole batch: same epoch losses, same parameters up to Adam's noise."""
+@pytest.mark.parametrize("exchange", ["rccl", "p2p"])
+def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, exchange):
+    """2 processes (both on cuda:0) each training half of every global batch of 8 vs one process training
+    the whole batch: same epoch losses, same parameters up to Adam's noise.  "rccl": torch.distributed
+    all-reduce between the phases (gloo here: two ranks cannot share a GPU under RCCL); "p2p": the
+    in-kernel exchange, step captured as a graph."""
     from ndivplanning_amd import train_gan
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cfg = _config(tmp_path, 16, "codes", 8, noise_source="device")
-    cfg.training.gan.use_graph = False
+    cfg.training.gan.use_graph = exchange == "p2p"
     # device noise is keyed by rank, so the comparison fixes the noise through the CPU stream:
     # not available across processes either -> compare the invariants instead
-    mp.spawn(_rank_main, args=(2, port, cfg.toDict(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_rank_main, args=(2, port, cfg.toDict(), str(tmp_path), exchange), nprocs=2, join=True)
     res = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(2)]
+    assert res[0]["p2p"] == (exchange == "p2p") and res[0]["graph"] == (exchange == "p2p")
     assert torch.equal(res[0]["g"], res[1]["g"]) and torch.equal(res[0]["d"], res[1]["d"])   # replicas in lockstep
     assert res[0]["hist"] == res[1]["hist"]
     d_avg, g_avg, div_avg = res[0]["hist"][0]
