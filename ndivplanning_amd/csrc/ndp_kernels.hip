@@ -606,22 +606,114 @@ struct PhaseAArgs {
   float* dy1seg; int seg_s, seg_entries;     // segment sums of dY1 (real + fake) [seg_entries x 64]
 };
 
-constexpr int phase_a_lds_floats(bool split) {
-  return (split ? 16 : 32) * (260 + TAILLD + 132 + 68 + 2) + 16 * 260 + 16 * 4 + 8;
+constexpr int phase_a_lds_floats(bool one_pass) {
+  return (one_pass ? 16 : 32) * (260 + TAILLD + 132 + 68 + 2) + 16 * 260 + 16 * 4 + 8;
+}
+
+// One D pass handled by a workgroup: which global pass (0 = real, 1 = fake), which 16-row tile.
+struct TilePass { int gp; int tile; int64_t row0; bool valid; };
+
+// D forward + BCE + D backward data path on NP stacked 16-row passes whose inputs are in XC (codes) and
+// XT (actions) and whose fc1 weights `dw1` are already in flight.  SEG_COMBINED: both passes belong to the
+// same tile and their dY1 segment sums are added (stacked phase A); otherwise every pass writes the sums
+// of its own tile into its global pass' half of the [2E] buffer.
+template <int NP, bool PK, int RG, bool SEG_COMBINED>
+__device__ __forceinline__ void phase_a_d_part(const PhaseAArgs& a, const TilePass (&pass)[NP], int ntiles,
+                                               FwdW<256, 64, 4, PK, RG>& dw1, float* XC, float* XT, float* B1,
+                                               float* B2, float* L, float* DL, float* red) {
+  constexpr int R = 16;
+  constexpr int DR = R * NP;
+  const DNet& d = a.d;
+  FwdW<64, 128, 4, PK, RG> dw2;
+  dw2.preload(PK ? d.pf2 : d.w2, 64, d.b2, nullptr, 0);
+  layer_fwd_run<NP, 256, 64, ACT_LRELU, 4, PK>(dw1, XC, 260, B2, 68, XT, TAILLD);      // D.h1 -> B2
+  __syncthreads();
+  FwdW<128, 256, 4, PK, RG> dw3;
+  dw3.preload(PK ? d.pf3 : d.w3, 128, d.b3, nullptr, 0);
+  layer_fwd_run<NP, 64, 128, ACT_LRELU, 4, PK>(dw2, B2, 68, B1, 132, nullptr, 0);      // D.h2 -> B1
+  __syncthreads();
+  layer_fwd_run<NP, 128, 256, ACT_LRELU, 4, PK>(dw3, B1, 132, XC, 260, nullptr, 0);    // D.h3 -> XC (code tile is dead)
+  __syncthreads();
+  layer_fwd_narrow<NP, 256, 1>(XC, 260, d.w4, d.b4, L, 1);
+  __syncthreads();
+  float lsum = 0.f;
+  if (threadIdx.x < DR) {
+    const int ps = threadIdx.x / R;
+    const TilePass q = (NP == 1 || ps == 0) ? pass[0] : pass[NP - 1];
+    const int64_t row = q.row0 + (threadIdx.x - ps * R);
+    const float target = q.gp == 0 ? 1.f : 0.f;                  // real: ones, fake: zeros (train_gan.py:174-181)
+    const float x = L[threadIdx.x];
+    float dl = 0.f;
+    if (row < a.m) {
+      lsum = fmaxf(x, 0.f) - x * target + log1pf(expf(-fabsf(x)));
+      dl = (1.f / (1.f + expf(-x)) - target) * a.inv_m;
+    }
+    DL[threadIdx.x] = dl;
+    if (q.valid) a.dl[(int64_t)q.gp * a.mpad + row] = dl;
+  }
+  {
+    const float tot = block_sum(lsum, red);
+    if (threadIdx.x == 0) a.loss_partials[blockIdx.x] = tot;
+  }
+  DgW<128, 256, PK, RG> dg3;
+  dg3.preload(PK ? d.pg3 : d.w3, 128);
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    if (!pass[ps].valid) continue;
+    const int64_t g0 = (int64_t)pass[ps].gp * a.mpad + pass[ps].row0;
+    store_tile<1, 64>(a.h1 + g0 * 64, 64, B2 + ps * R * 68, 68);
+    store_tile<1, 128>(a.h2 + g0 * 128, 128, B1 + ps * R * 132, 132);
+    store_tile<1, 256>(a.h3 + g0 * 256, 256, XC + ps * R * 260, 260);
+  }
+  if (threadIdx.x < DR) {
+    const int ps = threadIdx.x / R;
+    const TilePass q = (NP == 1 || ps == 0) ? pass[0] : pass[NP - 1];
+    const int64_t gr = (int64_t)q.gp * a.mpad + q.row0 + (threadIdx.x - ps * R);
+    if (q.valid) *reinterpret_cast<f32x4*>(a.xa + gr * 4) = *reinterpret_cast<const f32x4*>(XT + threadIdx.x * TAILLD);
+  }
+  __syncthreads();
+  layer_dgrad_narrow<NP, 256, 1, ACT_LRELU>(DL, 1, d.w4, XC, 260);                     // XC := dY3
+  __syncthreads();
+  DgW<64, 128, PK, RG> dg2;
+  dg2.preload(PK ? d.pg2 : d.w2, 64);
+  layer_dgrad_run<NP, 128, 256, ACT_LRELU, PK>(dg3, XC, 260, B1, 132);                 // B1 := dY2
+  __syncthreads();
+  layer_dgrad_run<NP, 64, 128, ACT_LRELU, PK>(dg2, B1, 132, B2, 68);                   // B2 := dY1
+  __syncthreads();
+  // segment sums of dY1 for the K-deduplicated fc1 weight gradient
+  if (SEG_COMBINED) {
+    store_segment_sums<64, NP>(B2, 68, a.dy1seg, pass[0].row0, a.code_rep, a.seg_s, a.seg_entries, pass[0].tile, ntiles);
+  } else {
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps)
+      if (pass[ps].valid)
+        store_segment_sums<64, 1>(B2 + ps * R * 68, 68, a.dy1seg + (size_t)pass[ps].gp * a.seg_entries * 64,
+                                  pass[ps].row0, a.code_rep, a.seg_s, a.seg_entries, pass[ps].tile, ntiles);
+  }
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    if (!pass[ps].valid) continue;
+    const int64_t g0 = (int64_t)pass[ps].gp * a.mpad + pass[ps].row0;
+    store_tile<1, 64>(a.dy1 + g0 * 64, 64, B2 + ps * R * 68, 68);
+    store_tile<1, 128>(a.dy2 + g0 * 128, 128, B1 + ps * R * 132, 132);
+    store_tile<1, 256>(a.dy3 + g0 * 256, 256, XC + ps * R * 260, 260);
+  }
 }
 
 // RG = VGPR budget of each weight prefetch ring: 96 keeps a lone workgroup per CU streaming at
 // small M; 32 with a 256-register cap lets two workgroups share a CU at large M.
 // SPLIT (small M, fewer tiles than CUs): the D step's real pass does not depend on G, so it runs
-// in workgroups of its own (blocks ntiles..2*ntiles-1, 16 rows each) on the CUs that have no tile,
-// beside the G-forward + D(fake) workgroups (blocks 0..ntiles-1): the critical path per tile drops
-// from G + 32 D rows to G + 16 D rows.  With more tiles than CUs the stacked form (!SPLIT: 16 real
-// + 16 fake rows share one stream of D's weights) is the better use of a CU.
-template <bool PK, int RG, bool SPLIT>
+// in workgroups of its own (role 1, blocks ntiles..) on the CUs that have no tile, beside the
+// G-forward + D(fake) workgroups (role 0, blocks 0..ntiles-1): the critical path per tile drops
+// from G + 32 D rows to G + 16 D rows.  PAIR: a role-1 workgroup stacks TWO real tiles (t, t + nh)
+// on one stream of D's weights, so that ntiles + ceil(ntiles / 2) <= 256 workgroups get a CU each
+// (the launch asks for more than half a CU's LDS to keep a second workgroup out) instead of 2 x ntiles
+// doubling up and slowing the role-0 workgroups.  With more tiles than CUs the stacked form (!SPLIT:
+// 16 real + 16 fake rows of the same tile in one workgroup) is the better use of a CU.
+template <bool PK, int RG, bool SPLIT, bool PAIR>
 __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseAArgs a) {
   constexpr int R = 16;
-  constexpr int NP = SPLIT ? 1 : 2;  // D passes handled by one workgroup
-  constexpr int DR = R * NP;         // D rows in LDS
+  constexpr int DR = (SPLIT && !PAIR) ? R : 2 * R;   // D rows the LDS regions are sized for
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XC = smem;                  // DR x 260
   float* XT = XC + DR * 260;         // DR x 16
@@ -632,10 +724,8 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseA
   float* L = A + 16 * 4;             // DR
   float* DL = L + DR;                // DR
   float* red = DL + DR;              // 8
-  const int ntiles = SPLIT ? (int)(gridDim.x >> 1) : (int)gridDim.x;
-  const int role = SPLIT ? (int)(blockIdx.x / ntiles) : 0;          // SPLIT: 0 = G + D(fake), 1 = D(real)
-  const int tile = SPLIT ? (int)(blockIdx.x - role * ntiles) : (int)blockIdx.x;
-  const int64_t row0 = (int64_t)tile * R;
+  const int ntiles = (int)(a.mpad / R);
+  const int role = SPLIT ? (int)((int)blockIdx.x >= ntiles) : 0;          // SPLIT: 0 = G + D(fake), 1 = D(real)
   const GNet& g = a.g;
   const DNet& d = a.d;
   NDP_STAMP_DECL;
@@ -643,6 +733,8 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseA
 
   FwdW<256, 64, 4, PK, RG> dw1;
   if (!SPLIT || role == 0) {
+    const int tile = (int)blockIdx.x;
+    const int64_t row0 = (int64_t)tile * R;
     // ---------------- G forward (rows 0..15 of the regions)
     FwdW<256, 128, 2, PK, RG> gw1;
     gw1.preload(PK ? g.pf1 : g.w1, g.ld1, g.b1, g.w1 + CODE, g.nz);
@@ -700,10 +792,11 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseA
     }
     __syncthreads();
     NDP_STAMP(2);
+    constexpr int FK = SPLIT ? 0 : 1;                                                     // LDS pass slot of the fake rows
     for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {                      // fake actions -> XT
       const int i = idx / TAILLD, t = idx % TAILLD;
       const int64_t row = row0 + i;
-      XT[((NP - 1) * R + i) * TAILLD + t] = (row < a.m && t < ADIM) ? A[i * 4 + t] : 0.f;
+      XT[(FK * R + i) * TAILLD + t] = (row < a.m && t < ADIM) ? A[i * 4 + t] : 0.f;
     }
     if (threadIdx.x < R) {
       const int64_t row = row0 + threadIdx.x;
@@ -711,96 +804,42 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseA
         *reinterpret_cast<f32x4*>(a.action_hat + row * 4) = *reinterpret_cast<const f32x4*>(A + threadIdx.x * 4);
     }
     __syncthreads();
+    // ---------------- D on the fake rows (split) or on real + fake rows (stacked)
+    if (SPLIT) {
+      const TilePass pass[1] = {{1, tile, row0, true}};
+      phase_a_d_part<1, PK, RG, false>(a, pass, ntiles, dw1, XC, XT, B1, B2, L, DL, red);
+    } else {
+      const TilePass pass[2] = {{0, tile, row0, true}, {1, tile, row0, true}};
+      phase_a_d_part<2, PK, RG, true>(a, pass, ntiles, dw1, XC, XT, B1, B2, L, DL, red);
+    }
   } else {
-    // ---------------- SPLIT, role 1: the real pass' inputs
+    // ---------------- SPLIT, role 1: the real pass of one tile, or of two stacked tiles (PAIR)
+    constexpr int NP = PAIR ? 2 : 1;
+    const int h = (int)blockIdx.x - ntiles, nh = (int)gridDim.x - ntiles;
+    TilePass pass[NP];
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const int t = h + ps * nh;
+      pass[ps].valid = t < ntiles;
+      pass[ps].gp = 0;
+      pass[ps].tile = pass[ps].valid ? t : 0;
+      pass[ps].row0 = pass[ps].valid ? (int64_t)t * R : a.mpad;     // rows >= m: zero inputs, zero loss, no stores
+    }
     dw1.preload(PK ? d.pf1 : d.w1 + ADIM, 260, d.b1, d.w1, ADIM);
-    for (int idx = threadIdx.x; idx < R * 64; idx += kThreads) {
+    for (int idx = threadIdx.x; idx < NP * R * 64; idx += kThreads) {
       const int i = idx >> 6, k = 4 * (idx & 63);
-      const int64_t row = row0 + i;
+      const int64_t row = ((NP == 1 || i < R) ? pass[0].row0 : pass[NP - 1].row0) + (i % R);
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (row < a.m) v = *reinterpret_cast<const f32x4*>(a.code + (row / a.code_rep) * CODE + k);
       *reinterpret_cast<f32x4*>(XC + i * 260 + k) = v;
     }
-    for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {
+    for (int idx = threadIdx.x; idx < NP * R * TAILLD; idx += kThreads) {
       const int i = idx / TAILLD, t = idx % TAILLD;
-      const int64_t row = row0 + i;
+      const int64_t row = ((NP == 1 || i < R) ? pass[0].row0 : pass[NP - 1].row0) + (i % R);
       XT[idx] = (row < a.m && t < ADIM) ? a.actions[(row / a.action_rep) * ADIM + t] : 0.f;
     }
     __syncthreads();
-  }
-  // pass p of this workgroup is global pass gp: stacked: p (0 real, 1 fake); split: role 0 -> fake, role 1 -> real
-  const int gp0 = SPLIT ? 1 - role : 0;
-
-  // ---------------- D on DR rows
-  FwdW<64, 128, 4, PK, RG> dw2;
-  dw2.preload(PK ? d.pf2 : d.w2, 64, d.b2, nullptr, 0);
-  layer_fwd_run<NP, 256, 64, ACT_LRELU, 4, PK>(dw1, XC, 260, B2, 68, XT, TAILLD);      // D.h1 -> B2
-  __syncthreads();
-  NDP_STAMP(3);
-  FwdW<128, 256, 4, PK, RG> dw3;
-  dw3.preload(PK ? d.pf3 : d.w3, 128, d.b3, nullptr, 0);
-  layer_fwd_run<NP, 64, 128, ACT_LRELU, 4, PK>(dw2, B2, 68, B1, 132, nullptr, 0);      // D.h2 -> B1
-  __syncthreads();
-  layer_fwd_run<NP, 128, 256, ACT_LRELU, 4, PK>(dw3, B1, 132, XC, 260, nullptr, 0);    // D.h3 -> XC (code tile is dead)
-  __syncthreads();
-  NDP_STAMP(4);
-  layer_fwd_narrow<NP, 256, 1>(XC, 260, d.w4, d.b4, L, 1);
-  __syncthreads();
-  float lsum = 0.f;
-  if (threadIdx.x < DR) {
-    const int ps = threadIdx.x / R;
-    const int gp = gp0 + ps;
-    const int64_t row = row0 + (threadIdx.x - ps * R);
-    const float target = gp == 0 ? 1.f : 0.f;                    // real: ones, fake: zeros (train_gan.py:174-181)
-    const float x = L[threadIdx.x];
-    float dl = 0.f;
-    if (row < a.m) {
-      lsum = fmaxf(x, 0.f) - x * target + log1pf(expf(-fabsf(x)));
-      dl = (1.f / (1.f + expf(-x)) - target) * a.inv_m;
-    }
-    DL[threadIdx.x] = dl;
-    a.dl[(int64_t)gp * a.mpad + row] = dl;
-  }
-  {
-    const float tot = block_sum(lsum, red);
-    if (threadIdx.x == 0) a.loss_partials[blockIdx.x] = tot;
-  }
-  NDP_STAMP(5);
-  DgW<128, 256, PK, RG> dg3;
-  dg3.preload(PK ? d.pg3 : d.w3, 128);
-#pragma unroll
-  for (int ps = 0; ps < NP; ++ps) {
-    const int64_t g0 = (int64_t)(gp0 + ps) * a.mpad + row0;
-    store_tile<1, 64>(a.h1 + g0 * 64, 64, B2 + ps * R * 68, 68);
-    store_tile<1, 128>(a.h2 + g0 * 128, 128, B1 + ps * R * 132, 132);
-    store_tile<1, 256>(a.h3 + g0 * 256, 256, XC + ps * R * 260, 260);
-  }
-  if (threadIdx.x < DR) {
-    const int ps = threadIdx.x / R;
-    const int64_t gr = (int64_t)(gp0 + ps) * a.mpad + row0 + (threadIdx.x - ps * R);
-    *reinterpret_cast<f32x4*>(a.xa + gr * 4) = *reinterpret_cast<const f32x4*>(XT + threadIdx.x * TAILLD);
-  }
-  __syncthreads();
-  NDP_STAMP(6);
-  layer_dgrad_narrow<NP, 256, 1, ACT_LRELU>(DL, 1, d.w4, XC, 260);                     // XC := dY3
-  __syncthreads();
-  DgW<64, 128, PK, RG> dg2;
-  dg2.preload(PK ? d.pg2 : d.w2, 64);
-  layer_dgrad_run<NP, 128, 256, ACT_LRELU, PK>(dg3, XC, 260, B1, 132);                 // B1 := dY2
-  __syncthreads();
-  NDP_STAMP(7);
-  layer_dgrad_run<NP, 64, 128, ACT_LRELU, PK>(dg2, B1, 132, B2, 68);                   // B2 := dY1
-  __syncthreads();
-  // segment sums of dY1 for the K-deduplicated fc1 weight gradient: stacked: real + fake summed
-  // into entries [0, E); split: this pass' half of a [2E] buffer
-  store_segment_sums<64, NP>(B2, 68, a.dy1seg + (SPLIT ? (size_t)gp0 * a.seg_entries * 64 : 0), row0, a.code_rep,
-                             a.seg_s, a.seg_entries, tile, ntiles);
-#pragma unroll
-  for (int ps = 0; ps < NP; ++ps) {
-    const int64_t g0 = (int64_t)(gp0 + ps) * a.mpad + row0;
-    store_tile<1, 64>(a.dy1 + g0 * 64, 64, B2 + ps * R * 68, 68);
-    store_tile<1, 128>(a.dy2 + g0 * 128, 128, B1 + ps * R * 132, 132);
-    store_tile<1, 256>(a.dy3 + g0 * 256, 256, XC + ps * R * 260, 260);
+    phase_a_d_part<NP, PK, RG, false>(a, pass, ntiles, dw1, XC, XT, B1, B2, L, DL, red);
   }
   NDP_STAMP(8);
   NDP_STAMP_FLUSH(9, 5);

@@ -29,7 +29,9 @@ def _rows(root, sql):
 
 def _label(name, seen):
     name = re.sub(r"\(.*$", "", name).replace("void ", "").strip()
-    if name in ("ndp::k_wgrad", "ndp::k_reduce_adam"):
+    base = re.sub(r"<.*>$", "", name)
+    if base in ("ndp::k_wgrad", "ndp::k_reduce_adam"):
+        name = base
         seen[name] += 1
         name += "[D]" if seen[name] % 2 == 1 else "[G]"
     return name
