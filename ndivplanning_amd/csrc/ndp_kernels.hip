@@ -25,7 +25,8 @@ __device__ int g_stamp_kernel = 0;   // which kernel flushes: 1 k_g_fwd, 2 k_d, 
 #define NDP_STAMP_ON(id) (g_stamps != nullptr && (g_stamp_kernel == 0 || g_stamp_kernel == (id)))
 // stamps are kept in LDS (a global store per stamp would sit in the wave's vmcnt queue and
 // delay the next counted wait) and flushed by NDP_STAMP_FLUSH at the end of the kernel
-#define NDP_STAMP_DECL __shared__ unsigned long long stamp_lds_[32]
+#define NDP_STAMP_DECL __shared__ unsigned long long stamp_store_[32]; unsigned long long* stamp_lds_ = stamp_store_
+#define NDP_STAMP_PTR stamp_lds_
 #define NDP_STAMP(i)                                             \
   do {                                                           \
     if (threadIdx.x == 0) {                                      \
@@ -41,6 +42,7 @@ __device__ int g_stamp_kernel = 0;   // which kernel flushes: 1 k_g_fwd, 2 k_d, 
   } while (0)
 #else
 #define NDP_STAMP_DECL
+#define NDP_STAMP_PTR nullptr
 #define NDP_STAMP(i) do { } while (0)
 #define NDP_STAMP_FLUSH(n, id) do { } while (0)
 #endif
@@ -620,20 +622,26 @@ struct TilePass { int gp; int tile; int64_t row0; bool valid; };
 template <int NP, bool PK, int RG, bool SEG_COMBINED>
 __device__ __forceinline__ void phase_a_d_part(const PhaseAArgs& a, const TilePass (&pass)[NP], int ntiles,
                                                FwdW<256, 64, 4, PK, RG>& dw1, float* XC, float* XT, float* B1,
-                                               float* B2, float* L, float* DL, float* red) {
+                                               float* B2, float* L, float* DL, float* red,
+                                               unsigned long long* stamp_lds_) {
   constexpr int R = 16;
   constexpr int DR = R * NP;
   const DNet& d = a.d;
+  (void)stamp_lds_;
   FwdW<64, 128, 4, PK, RG> dw2;
   dw2.preload(PK ? d.pf2 : d.w2, 64, d.b2, nullptr, 0);
+  NDP_STAMP(10);
   layer_fwd_run<NP, 256, 64, ACT_LRELU, 4, PK>(dw1, XC, 260, B2, 68, XT, TAILLD);      // D.h1 -> B2
+  NDP_STAMP(11);
   __syncthreads();
+  NDP_STAMP(3);
   FwdW<128, 256, 4, PK, RG> dw3;
   dw3.preload(PK ? d.pf3 : d.w3, 128, d.b3, nullptr, 0);
   layer_fwd_run<NP, 64, 128, ACT_LRELU, 4, PK>(dw2, B2, 68, B1, 132, nullptr, 0);      // D.h2 -> B1
   __syncthreads();
   layer_fwd_run<NP, 128, 256, ACT_LRELU, 4, PK>(dw3, B1, 132, XC, 260, nullptr, 0);    // D.h3 -> XC (code tile is dead)
   __syncthreads();
+  NDP_STAMP(4);
   layer_fwd_narrow<NP, 256, 1>(XC, 260, d.w4, d.b4, L, 1);
   __syncthreads();
   float lsum = 0.f;
@@ -655,6 +663,7 @@ __device__ __forceinline__ void phase_a_d_part(const PhaseAArgs& a, const TilePa
     const float tot = block_sum(lsum, red);
     if (threadIdx.x == 0) a.loss_partials[blockIdx.x] = tot;
   }
+  NDP_STAMP(5);
   DgW<128, 256, PK, RG> dg3;
   dg3.preload(PK ? d.pg3 : d.w3, 128);
 #pragma unroll
@@ -672,12 +681,14 @@ __device__ __forceinline__ void phase_a_d_part(const PhaseAArgs& a, const TilePa
     if (q.valid) *reinterpret_cast<f32x4*>(a.xa + gr * 4) = *reinterpret_cast<const f32x4*>(XT + threadIdx.x * TAILLD);
   }
   __syncthreads();
+  NDP_STAMP(6);
   layer_dgrad_narrow<NP, 256, 1, ACT_LRELU>(DL, 1, d.w4, XC, 260);                     // XC := dY3
   __syncthreads();
   DgW<64, 128, PK, RG> dg2;
   dg2.preload(PK ? d.pg2 : d.w2, 64);
   layer_dgrad_run<NP, 128, 256, ACT_LRELU, PK>(dg3, XC, 260, B1, 132);                 // B1 := dY2
   __syncthreads();
+  NDP_STAMP(7);
   layer_dgrad_run<NP, 64, 128, ACT_LRELU, PK>(dg2, B1, 132, B2, 68);                   // B2 := dY1
   __syncthreads();
   // segment sums of dY1 for the K-deduplicated fc1 weight gradient
@@ -804,13 +815,14 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseA
         *reinterpret_cast<f32x4*>(a.action_hat + row * 4) = *reinterpret_cast<const f32x4*>(A + threadIdx.x * 4);
     }
     __syncthreads();
+    NDP_STAMP(9);
     // ---------------- D on the fake rows (split) or on real + fake rows (stacked)
     if (SPLIT) {
       const TilePass pass[1] = {{1, tile, row0, true}};
-      phase_a_d_part<1, PK, RG, false>(a, pass, ntiles, dw1, XC, XT, B1, B2, L, DL, red);
+      phase_a_d_part<1, PK, RG, false>(a, pass, ntiles, dw1, XC, XT, B1, B2, L, DL, red, NDP_STAMP_PTR);
     } else {
       const TilePass pass[2] = {{0, tile, row0, true}, {1, tile, row0, true}};
-      phase_a_d_part<2, PK, RG, true>(a, pass, ntiles, dw1, XC, XT, B1, B2, L, DL, red);
+      phase_a_d_part<2, PK, RG, true>(a, pass, ntiles, dw1, XC, XT, B1, B2, L, DL, red, NDP_STAMP_PTR);
     }
   } else {
     // ---------------- SPLIT, role 1: the real pass of one tile, or of two stacked tiles (PAIR)
@@ -839,10 +851,10 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseA
       XT[idx] = (row < a.m && t < ADIM) ? a.actions[(row / a.action_rep) * ADIM + t] : 0.f;
     }
     __syncthreads();
-    phase_a_d_part<NP, PK, RG, false>(a, pass, ntiles, dw1, XC, XT, B1, B2, L, DL, red);
+    phase_a_d_part<NP, PK, RG, false>(a, pass, ntiles, dw1, XC, XT, B1, B2, L, DL, red, NDP_STAMP_PTR);
   }
   NDP_STAMP(8);
-  NDP_STAMP_FLUSH(9, 5);
+  NDP_STAMP_FLUSH(12, 5);
 }
 
 // Phase B (train_gan.py:187-202) for one 16-row tile: D' forward with the updated D, G loss,
@@ -1332,6 +1344,7 @@ __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& 
   p = p - step_size * (m / denom);              // param.addcdiv_(exp_avg, denom, -step_size)
 }
 
+template <bool P2P>
 __global__ __launch_bounds__(kThreads) void k_reduce_adam(ReduceArgs a) {
   __shared__ float sh[8];
   const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
@@ -1356,7 +1369,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce_adam(ReduceArgs a) {
       for (int u = 0; u < 16; ++u) g += t[u];
     }
   }
-  if (a.p2p.world > 1) g = p2p_sum(a.p2p, g, p, p < a.n, (uint32_t)a.step[0]);   // uniform branch
+  if constexpr (P2P) g = p2p_sum(a.p2p, g, p, p < a.n, (uint32_t)a.step[0]);     // sum over ranks
   if (p < a.n) {
     if (a.grad != nullptr) a.grad[p] = g;
     if (a.params != nullptr) {

@@ -34,17 +34,19 @@ stamps = torch.zeros(4096 * 32, dtype=torch.int64, device=dev)
 KID = {"g": 1, "ga": 1, "d": 2, "da": 2, "db": 2, "w": 4, "wa": 4, "wb": 4, "pa": 5}
 assert raw.ndp_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()), KID.get(os.environ.get("WHICH", "g"), 0)) == 0
 
-def report(name, fn, nphase, nwg):
+def report(name, fn, nphase, nwg, first=0, skip=()):
     for _ in range(int(os.environ.get("WARM", "0"))):
         fn()
     stamps.zero_(); torch.cuda.synchronize()
     fn(); torch.cuda.synchronize()
-    s = stamps.cpu().numpy().reshape(-1, 16, 2)[:nwg]
+    s = stamps.cpu().numpy().reshape(-1, 16, 2)[first:first + nwg]
     clk, wall = s[:, :, 0].astype(np.float64), s[:, :, 1].astype(np.float64)
     t0 = wall[:, 0].min()
     print("%s: %d workgroups; first start -> last end %.2f us; start skew %.2f us" % (
         name, nwg, (wall[:, nphase].max() - t0) / 100.0, (wall[:, 0].max() - t0) / 100.0))
     for i in range(nphase):
+        if i in skip or i + 1 in skip:
+            continue
         dw = (wall[:, i + 1] - wall[:, i]) / 100.0
         dc = clk[:, i + 1] - clk[:, i]
         print("   phase %2d: median %.2f us (max %.2f)  %8.0f shader cycles  => %.2f GHz" % (
@@ -72,8 +74,22 @@ elif which == "wb":
     tr._phase_a(True)
     report("k_wgrad[G] [0 setup,1 main loop,2 lds write,3 reduce+store]", lambda: tr._phase_b(), 4, 26 * nch)
 elif which == "pa":
-    report("k_phase_a [0 load,1 G fc1..fc4+fc5,2 a_hat->XT,3 D fc1,4 D fc2+fc3,5 D fc4+loss,6 stores,7 dg4+dg3,8 dg2+stores]",
+    report("k_phase_a role 0 [0 load,1 G fc1..fc4+fc5,2 a_hat->XT,3 D fc1,4 D fc2+fc3,5 D fc4+loss,6 stores,7 dg4+dg3,8 dg2+stores]",
            lambda: tr._phase_a(True), 8, mpad // 16)
+    nt = mpad // 16
+    w0 = stamps.cpu().numpy().reshape(-1, 16, 2)[:nt][:, :, 1].astype(np.float64)
+    print("role 0, inside phase 2->3: a_hat->XT + sync %.2f us | dw2.preload issue %.2f | fc1 k-loop+epilogue (wave 0) %.2f | barrier %.2f"
+          % tuple(np.median(w0[:, b] - w0[:, a_]) / 100 for a_, b in ((2, 9), (9, 10), (10, 11), (11, 3))))
+    if 128 < nt and nt + (nt + 1) // 2 <= 256:
+        s = stamps.cpu().numpy().reshape(-1, 16, 2)[nt:nt + (nt + 1) // 2]
+        wall = s[:, :, 1].astype(np.float64)
+        all_ = stamps.cpu().numpy().reshape(-1, 16, 2)[:nt + (nt + 1) // 2][:, :, 1].astype(np.float64)
+        t0 = all_[:, 0].min()
+        print("role 1 (paired real tiles): start median %.2f us after first start, end median %.2f (max %.2f); D fc1 done at %.2f, fwd done %.2f"
+              % (np.median(wall[:, 0] - t0) / 100, np.median(wall[:, 8] - t0) / 100, (wall[:, 8] - t0).max() / 100,
+                 np.median(wall[:, 3] - t0) / 100, np.median(wall[:, 4] - t0) / 100))
+        r0 = all_[:nt]
+        print("role 0: end median %.2f us (max %.2f)" % (np.median(r0[:, 8] - t0) / 100, (r0[:, 8] - t0).max() / 100))
 elif which == "ga":
     report("k_g_fwd in phase A (packed weights) [0 load,1 fc1,2 fc2,3 fc3,4 fc4,5 fc5,6 store]",
            lambda: tr._phase_a(True), 7, mpad // (16 * rt))
