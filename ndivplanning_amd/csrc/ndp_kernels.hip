@@ -1289,17 +1289,23 @@ __device__ __forceinline__ float p2p_sum(const P2PArgs& x, float g, int64_t p, b
       if (r < W && r != me)
         __hip_atomic_store(reinterpret_cast<float*>(x.region[r]) + at, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  __threadfence_system();               // this thread's pushes are visible system-wide ...
-  __syncthreads();                      // ... and so are the whole workgroup's, before any flag goes out
+  // No system-scope fence: on this part it writes back / invalidates the whole L2 (measured ~27 ns per wave
+  // and fence, x 8 per workgroup x 228-328 workgroups), and nothing here is cached -- the regions are
+  // uncached memory and every access below is a system-scope atomic (sc0 sc1: bypasses L1 and L2).  What
+  // the protocol needs is that the workgroup's pushes are ACKNOWLEDGED before a flag goes out: the
+  // workgroup-scope release is the s_waitcnt vmcnt(0), the barrier collects all four waves.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (a workgroup-scope release alone does not wait for the acks)
+  __syncthreads();
   const int t = threadIdx.x;
   if (t < W && t != me) {
     const int64_t fbase = kP2PFlagOff + (int64_t)x.net * kP2PRanks * kP2PBlocks + blockIdx.x;
-    __hip_atomic_store(x.region[t] + fbase + (int64_t)me * kP2PBlocks, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(x.region[t] + fbase + (int64_t)me * kP2PBlocks, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     uint32_t* status = x.region[me];
     const uint32_t* flag = x.region[me] + fbase + (int64_t)t * kP2PBlocks;
     if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) {
       const long long t0 = wall_clock64();
-      while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - step) < 0) {
+      while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - step) < 0) {
         if (wall_clock64() - t0 > x.timeout_ticks) {     // exit condition every wave reaches
           __hip_atomic_store(status, (uint32_t)(1 + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           break;
@@ -1308,19 +1314,19 @@ __device__ __forceinline__ float p2p_sum(const P2PArgs& x, float g, int64_t p, b
       }
     }
   }
-  __syncthreads();
-  __threadfence_system();               // acquire side for the threads that did not poll
+  __syncthreads();                      // the inbox loads below are issued after the flags were seen
+  // unconditional loads (a branch around a load makes hipcc wait for each one in turn): slots of ranks
+  // that do not exist read this rank's own, unused, slot; p < cap always
   float v[kP2PRanks];
+  const float* own = reinterpret_cast<const float*>(x.region[me]) + inbox + par + p;
 #pragma unroll
   for (int r = 0; r < kP2PRanks; ++r)
-    v[r] = (valid && r < W && r != me)
-               ? __hip_atomic_load(reinterpret_cast<const float*>(x.region[me]) + inbox + (int64_t)r * 2 * cap + par + p,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-               : 0.f;
+    v[r] = __hip_atomic_load(own + (int64_t)(r < W ? r : me) * 2 * cap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   float s = 0.f;                        // rank order 0..W-1 on every rank: bit-identical replicas
 #pragma unroll
   for (int r = 0; r < kP2PRanks; ++r)
     if (r < W) s += (r == me) ? g : v[r];
+  (void)valid;
   return s;
 }
 
