@@ -420,6 +420,34 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, size_t gld,
   }
 }
 
+// A global tile [16 RT x W] held in registers between its loads (issued early) and its LDS writes (done where
+// the data is needed, when the loads have long returned): the early loads do not hold up an earlier barrier.
+template <int RT, int W>
+struct TileRegs {
+  static constexpr int NV = 16 * RT * W / 4;
+  static constexpr int N = (NV + kThreads - 1) / kThreads;
+  f32x4 v[N];
+  __device__ __forceinline__ void load(const float* __restrict__ src, size_t gld) {
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      int idx = threadIdx.x + u * kThreads;
+      idx = idx < NV ? idx : NV - 1;                      // unconditional load (clamped), see wgrad
+      const int row = idx / (W / 4), k = 4 * (idx % (W / 4));
+      v[u] = ldg4<4>(src + (size_t)row * gld + k);
+    }
+  }
+  __device__ __forceinline__ void store(float* dst, int ld) const {
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      const int idx = threadIdx.x + u * kThreads;
+      if (idx < NV) {
+        const int row = idx / (W / 4), k = 4 * (idx % (W / 4));
+        *reinterpret_cast<f32x4*>(dst + row * ld + k) = v[u];
+      }
+    }
+  }
+};
+
 template <int RT, int W>
 __device__ __forceinline__ void load_tile(float* dst, int ld,
                                           const float* __restrict__ src, size_t gld) {

@@ -873,9 +873,17 @@ struct PhaseBArgs {
   float* dy1seg; int seg_s, seg_entries;     // segment sums of G's dY1 [seg_entries x 128]
 };
 
-constexpr int phase_b_lds_floats() { return 16 * (260 + TAILLD + 132 + 68 + 132 + 4 + 2) + 8; }
+// pre: G's saved activations h2..h4 and the action columns of D.fc1 are fetched into LDS regions of their own at
+// the start of the kernel (+30 KB) instead of into the dead D regions in the middle of it
+constexpr int phase_b_lds_floats(bool pre) {
+  return 16 * (260 + TAILLD + 132 + 68 + 132 + 4 + 2) + 8 + (pre ? 256 + 16 * (260 + 132 + 68) : 0);
+}
 
-template <bool PK, int RG>
+// PRE (one workgroup per CU, small M): the loads of G's activations for the backward half are issued with the
+// input tile, so the ~2.6 us round trip in the middle of the kernel (global -> LDS -> barrier, measured with
+// stamps) overlaps the D' half; with several workgroups per CU (large M) other workgroups hide it and the LDS
+// is better spent on residency.
+template <bool PK, int RG, bool PRE>
 __global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseBArgs a) {
   constexpr int R = 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -888,9 +896,15 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseB
   float* L = DA + R * 4;             // 16
   float* DL = L + R;                 // 16
   float* red = DL + R;               // 8
+  float* W1A = red + 8;              // PRE: 64 x 4 action columns of D.fc1
+  float* G4 = PRE ? W1A + 256 : XC;  // G.h4 / dY4   (!PRE: the D regions, loaded when they are dead)
+  float* G3 = PRE ? G4 + R * 260 : B1;
+  float* G2 = PRE ? G3 + R * 132 : B2;
   const int64_t row0 = (int64_t)blockIdx.x * R;
   const GNet& g = a.g;
   const DNet& d = a.d;
+  NDP_STAMP_DECL;
+  NDP_STAMP(0);
 
   FwdW<256, 64, 4, PK, RG> dw1;
   dw1.preload(PK ? d.pf1 : d.w1 + ADIM, 260, d.b1, d.w1, ADIM);
@@ -906,11 +920,35 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseB
     const int64_t row = row0 + i;
     XT[idx] = (row < a.m && t < ADIM) ? a.action_hat[row * ADIM + t] : 0.f;
   }
-  load_tile<1, 128>(H1, 132, a.gh1 + row0 * 128, 128);                                   // needed last; region is free
+  // G's saved activations: PRE keeps them in registers until D'.fc1 is done (their loads are issued now, behind
+  // the input tile, and nothing waits for them here)
+  TileRegs<1, 128> t1;
+  TileRegs<1, 256> t4;
+  TileRegs<1, 128> t3;
+  TileRegs<1, 64> t2;
+  float w1a = 0.f;
+  if (PRE) {
+    t1.load(a.gh1 + row0 * 128, 128);
+    t4.load(a.gh4 + row0 * 256, 256);
+    t3.load(a.gh3 + row0 * 128, 128);
+    t2.load(a.gh2 + row0 * 64, 64);
+    w1a = d.w1[(threadIdx.x >> 2) * 260 + (threadIdx.x & 3)];
+    pin_vmem();
+  } else {
+    load_tile<1, 128>(H1, 132, a.gh1 + row0 * 128, 128);                                 // needed last; region is free
+  }
   __syncthreads();
+  NDP_STAMP(1);
   FwdW<64, 128, 4, PK, RG> dw2;
   dw2.preload(PK ? d.pf2 : d.w2, 64, d.b2, nullptr, 0);
   layer_fwd_run<1, 256, 64, ACT_LRELU, 4, PK>(dw1, XC, 260, B2, 68, XT, TAILLD);        // D.h1 -> B2
+  if (PRE) {                                                                             // regions of their own: no hazard
+    t1.store(H1, 132);
+    t4.store(G4, 260);
+    t3.store(G3, 132);
+    t2.store(G2, 68);
+    W1A[threadIdx.x] = w1a;
+  }
   __syncthreads();
   FwdW<128, 256, 4, PK, RG> dw3;
   dw3.preload(PK ? d.pf3 : d.w3, 128, d.b3, nullptr, 0);
@@ -918,6 +956,7 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseB
   __syncthreads();
   layer_fwd_run<1, 128, 256, ACT_LRELU, 4, PK>(dw3, B1, 132, XC, 260, nullptr, 0);      // D.h3 -> XC
   __syncthreads();
+  NDP_STAMP(2);
   layer_fwd_narrow<1, 256, 1>(XC, 260, d.w4, d.b4, L, 1);
   __syncthreads();
   float lsum = 0.f;
@@ -935,6 +974,7 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseB
     const float tot = block_sum(lsum, red);
     if (threadIdx.x == 0) a.loss_partials[blockIdx.x] = tot;
   }
+  NDP_STAMP(3);
   DgW<128, 256, PK, RG> dg3;
   dg3.preload(PK ? d.pg3 : d.w3, 128);
   layer_dgrad_narrow<1, 256, 1, ACT_LRELU>(DL, 1, d.w4, XC, 260);                       // XC := D.dY3
@@ -945,13 +985,14 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseB
   __syncthreads();
   layer_dgrad_run<1, 64, 128, ACT_LRELU, PK>(dg2, B1, 132, B2, 68);                     // B2 := D.dY1
   __syncthreads();
+  NDP_STAMP(4);
   // dLoss/d action_hat = D.dY1 . W1[:, 0:4] (+ NDiv gradient) -> DA and dy5
   if (threadIdx.x < R * ADIM) {
     const int i = threadIdx.x >> 2, j = threadIdx.x & 3;
     const int64_t row = row0 + i;
     float s = 0.f;
 #pragma unroll 8
-    for (int o = 0; o < 64; ++o) s = fmaf(B2[i * 68 + o], d.w1[o * 260 + j], s);
+    for (int o = 0; o < 64; ++o) s = fmaf(B2[i * 68 + o], PRE ? W1A[o * 4 + j] : d.w1[o * 260 + j], s);
     if (row < a.m) {
       if (a.nd_grad != nullptr) s += a.nd_grad[row * ADIM + j];
     } else {
@@ -961,31 +1002,41 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseB
     a.dy5[row * ADIM + j] = s;
   }
   __syncthreads();
+  NDP_STAMP(5);
 
-  // ---------------- G backward data path (regions XC, B1, B2 are free again)
+  // ---------------- G backward data path (!PRE: regions XC, B1, B2 are free again and take G's activations)
   DgW<128, 256, PK, RG> gg4;
   gg4.preload(PK ? g.pg4 : g.w4, 128);
-  load_tile<1, 256>(XC, 260, a.gh4 + row0 * 256, 256);
-  load_tile<1, 128>(B1, 132, a.gh3 + row0 * 128, 128);
-  load_tile<1, 64>(B2, 68, a.gh2 + row0 * 64, 64);
+  if (!PRE) {
+    load_tile<1, 256>(G4, 260, a.gh4 + row0 * 256, 256);
+    load_tile<1, 128>(G3, 132, a.gh3 + row0 * 128, 128);
+    load_tile<1, 64>(G2, 68, a.gh2 + row0 * 64, 64);
+    __syncthreads();
+  }
+  NDP_STAMP(6);
+  layer_dgrad_narrow<1, 256, 4, ACT_RELU>(DA, 4, g.w5, G4, 260);                        // G4 := G.dY4
   __syncthreads();
-  layer_dgrad_narrow<1, 256, 4, ACT_RELU>(DA, 4, g.w5, XC, 260);                        // XC := G.dY4
-  __syncthreads();
+  NDP_STAMP(7);
   DgW<64, 128, PK, RG> gg3;
   gg3.preload(PK ? g.pg3 : g.w3, 64);
-  layer_dgrad_run<1, 128, 256, ACT_RELU, PK>(gg4, XC, 260, B1, 132);                    // B1 := G.dY3
+  layer_dgrad_run<1, 128, 256, ACT_RELU, PK>(gg4, G4, 260, G3, 132);                    // G3 := G.dY3
   __syncthreads();
+  NDP_STAMP(8);
   DgW<128, 64, PK, RG> gg2;
   gg2.preload(PK ? g.pg2 : g.w2, 128);
-  store_tile<1, 256>(a.dy4 + row0 * 256, 256, XC, 260);
-  layer_dgrad_run<1, 64, 128, ACT_RELU, PK>(gg3, B1, 132, B2, 68);                      // B2 := G.dY2
+  store_tile<1, 256>(a.dy4 + row0 * 256, 256, G4, 260);
+  layer_dgrad_run<1, 64, 128, ACT_RELU, PK>(gg3, G3, 132, G2, 68);                      // G2 := G.dY2
   __syncthreads();
-  store_tile<1, 128>(a.dy3 + row0 * 128, 128, B1, 132);
-  layer_dgrad_run<1, 128, 64, ACT_RELU, PK>(gg2, B2, 68, H1, 132);                      // H1 := G.dY1
+  NDP_STAMP(9);
+  store_tile<1, 128>(a.dy3 + row0 * 128, 128, G3, 132);
+  layer_dgrad_run<1, 128, 64, ACT_RELU, PK>(gg2, G2, 68, H1, 132);                      // H1 := G.dY1
   __syncthreads();
-  store_tile<1, 64>(a.dy2 + row0 * 64, 64, B2, 68);
+  NDP_STAMP(10);
+  store_tile<1, 64>(a.dy2 + row0 * 64, 64, G2, 68);
   store_tile<1, 128>(a.dy1 + row0 * 128, 128, H1, 132);
   store_segment_sums<128, 1>(H1, 132, a.dy1seg, row0, a.code_rep, a.seg_s, a.seg_entries, (int)blockIdx.x, (int)gridDim.x);
+  NDP_STAMP(11);
+  NDP_STAMP_FLUSH(12, 6);
 }
 
 // Adam state word: {int32 step, float lr/(1-b1^t), float sqrt(1-b2^t), pad}.  One thread

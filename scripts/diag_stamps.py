@@ -31,7 +31,7 @@ for _ in range(20):
     tr.step()
 torch.cuda.synchronize()
 stamps = torch.zeros(4096 * 32, dtype=torch.int64, device=dev)
-KID = {"g": 1, "ga": 1, "d": 2, "da": 2, "db": 2, "w": 4, "wa": 4, "wb": 4, "pa": 5}
+KID = {"g": 1, "ga": 1, "d": 2, "da": 2, "db": 2, "w": 4, "wa": 4, "wb": 4, "pa": 5, "pb": 6}
 assert raw.ndp_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()), KID.get(os.environ.get("WHICH", "g"), 0)) == 0
 
 def report(name, fn, nphase, nwg, first=0, skip=()):
@@ -90,6 +90,10 @@ elif which == "pa":
                  np.median(wall[:, 3] - t0) / 100, np.median(wall[:, 4] - t0) / 100))
         r0 = all_[:nt]
         print("role 0: end median %.2f us (max %.2f)" % (np.median(r0[:, 8] - t0) / 100, (r0[:, 8] - t0).max() / 100))
+elif which == "pb":
+    tr._phase_a(True)
+    report("k_phase_b [0 load,1 D' fwd fc1-3,2 fc4+loss,3 D' dgrad,4 dA,5 G acts load,6 dY4 narrow,7 gg4,8 gg3,9 gg2,10 stores]",
+           lambda: tr._phase_b(), 11, mpad // 16)
 elif which == "ga":
     report("k_g_fwd in phase A (packed weights) [0 load,1 fc1,2 fc2,3 fc3,4 fc4,5 fc5,6 store]",
            lambda: tr._phase_a(True), 7, mpad // (16 * rt))
