@@ -659,8 +659,8 @@ __device__ __forceinline__ void phase_a_d_part(const PhaseAArgs& a, const TilePa
     DL[threadIdx.x] = dl;
     if (q.valid) a.dl[(int64_t)q.gp * a.mpad + row] = dl;
   }
-  {
-    const float tot = block_sum(lsum, red);
+  if (threadIdx.x < 64) {               // the rows' losses all sit in wave 0 (DR <= 32): no block-wide reduction
+    const float tot = wave_sum(lsum);
     if (threadIdx.x == 0) a.loss_partials[blockIdx.x] = tot;
   }
   NDP_STAMP(5);
@@ -777,20 +777,24 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseA
     gw2.preload(PK ? g.pf2 : g.w2, 128, g.b2, nullptr, 0);
     layer_fwd_run<1, 256, 128, ACT_RELU, 2, PK>(gw1, XC, 260, B1, 132, XT, TAILLD);      // h1 -> B1
     __syncthreads();
+    NDP_STAMP(12);
     FwdW<64, 128, 4, PK, RG> gw3;
     gw3.preload(PK ? g.pf3 : g.w3, 64, g.b3, nullptr, 0);
     store_tile<1, 128>(a.gh1 + row0 * 128, 128, B1, 132);
     layer_fwd_run<1, 128, 64, ACT_RELU, 4, PK>(gw2, B1, 132, B2, 68, nullptr, 0);        // h2 -> B2
     __syncthreads();
+    NDP_STAMP(13);
     FwdW<128, 256, 4, PK, RG> gw4;
     gw4.preload(PK ? g.pf4 : g.w4, 128, g.b4, nullptr, 0);
     store_tile<1, 64>(a.gh2 + row0 * 64, 64, B2, 68);
     layer_fwd_run<1, 64, 128, ACT_RELU, 4, PK>(gw3, B2, 68, B1, 132, nullptr, 0);        // h3 -> B1 (h1 is stored)
     __syncthreads();
+    NDP_STAMP(14);
     dw1.preload(PK ? d.pf1 : d.w1 + ADIM, 260, d.b1, d.w1, ADIM);                         // D fc1 weights fly early
     store_tile<1, 128>(a.gh3 + row0 * 128, 128, B1, 132);
     layer_fwd_run<1, 128, 256, ACT_RELU, 4, PK>(gw4, B1, 132, B3, 260, nullptr, 0);      // h4 -> B3
     __syncthreads();
+    NDP_STAMP(15);
     store_tile<1, 256>(a.gh4 + row0 * 256, 256, B3, 260);
     layer_fwd_narrow<1, 256, 4>(B3, 260, g.w5, g.b5, A, 4);                               // action_hat -> A
     if (!SPLIT) {
@@ -854,7 +858,7 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseA
     phase_a_d_part<NP, PK, RG, false>(a, pass, ntiles, dw1, XC, XT, B1, B2, L, DL, red, NDP_STAMP_PTR);
   }
   NDP_STAMP(8);
-  NDP_STAMP_FLUSH(12, 5);
+  NDP_STAMP_FLUSH(16, 5);
 }
 
 // Phase B (train_gan.py:187-202) for one 16-row tile: D' forward with the updated D, G loss,
@@ -970,10 +974,11 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseB
     }
     DL[threadIdx.x] = dl;
   }
-  {
-    const float tot = block_sum(lsum, red);
+  if (threadIdx.x < 64) {               // the 16 rows' losses all sit in wave 0: no block-wide reduction
+    const float tot = wave_sum(lsum);
     if (threadIdx.x == 0) a.loss_partials[blockIdx.x] = tot;
   }
+  __syncthreads();                      // DL
   NDP_STAMP(3);
   DgW<128, 256, PK, RG> dg3;
   dg3.preload(PK ? d.pg3 : d.w3, 128);

@@ -80,6 +80,8 @@ elif which == "pa":
     w0 = stamps.cpu().numpy().reshape(-1, 16, 2)[:nt][:, :, 1].astype(np.float64)
     print("role 0, inside phase 2->3: a_hat->XT + sync %.2f us | dw2.preload issue %.2f | fc1 k-loop+epilogue (wave 0) %.2f | barrier %.2f"
           % tuple(np.median(w0[:, b] - w0[:, a_]) / 100 for a_, b in ((2, 9), (9, 10), (10, 11), (11, 3))))
+    print("role 0, G forward: fc1 %.2f us | fc2 %.2f | fc3 %.2f | fc4 %.2f | store h4 + fc5 + actions %.2f"
+          % tuple(np.median(w0[:, b] - w0[:, a_]) / 100 for a_, b in ((1, 12), (12, 13), (13, 14), (14, 15), (15, 2))))
     if 128 < nt and nt + (nt + 1) // 2 <= 256:
         s = stamps.cpu().numpy().reshape(-1, 16, 2)[nt:nt + (nt + 1) // 2]
         wall = s[:, :, 1].astype(np.float64)
