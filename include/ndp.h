@@ -234,8 +234,10 @@ int ndp_uniform_noise(float *out, int64_t n, uint64_t seed, const int32_t *offse
  * with hipIpc and mapped by every peer.  One exchange, inside the kernel that
  * has just summed the rank's split-K slabs:
  *   push   each workgroup stores its 256 gradient values into the inbox slot
- *          [src = this rank][step parity] of EVERY peer's region, fences at
- *          system scope, then releases flag[src][workgroup] = step there;
+ *          [src = this rank][step parity] of EVERY peer's region, waits for the
+ *          stores to be acknowledged, then sets flag[src][workgroup] = step there
+ *          (all accesses are system-scope atomics on uncached memory: no cache
+ *          maintenance, no fences);
  *   wait   it polls the flags the peers set in its OWN region (bounded by
  *          timeout_ms: on expiry the region's status word is set, the wait is
  *          skipped from then on and ndp_p2p_status reports it -- never a hang);
