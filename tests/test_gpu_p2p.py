@@ -25,7 +25,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _make_trainer(flat, flat_global, p2p, nslots=1, use_graph=True):
+def _make_trainer(flat, flat_global, p2p, nslots=1, use_graph=True, dsteps=1):
     from ndivplanning_amd.models.gan import Decoder, Discriminator
     from ndivplanning_amd.trainer import GanTrainer
     g0, d0 = O.init_params(0, NZ)
@@ -33,7 +33,7 @@ def _make_trainer(flat, flat_global, p2p, nslots=1, use_graph=True):
     dec.load_state_dict(g0)
     dis.load_state_dict(d0)
     return GanTrainer(dec, dis, flat=flat, num_sample=K, flat_global=flat_global, p2p=p2p, use_graph=use_graph,
-                      steps_per_launch=nslots)
+                      steps_per_launch=nslots, discrim_steps=dsteps)
 
 
 def _rank_main(rank, world, port, out_dir):
@@ -148,3 +148,44 @@ def _timeout_main(rank, world, port, out_dir):
     torch.save(res, os.path.join(out_dir, "t%d.pt" % rank))
     p2p.close()
     dist.destroy_process_group()
+
+
+def _dsteps_main(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", NDP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from ndivplanning_amd import dp
+    torch.cuda.set_device(0)
+    dp.init_process_group("cuda:0")
+    p2p = dp.P2PExchange("cuda:0", timeout_ms=20000)
+    codes, actions, noise = O.synthetic_batch(12, BATCH_GLOBAL, K, NZ, steps=3)
+    lo, hi = dp.shard_bounds(codes.shape[0], rank, world)
+    t = _make_trainer(hi - lo, codes.shape[0], p2p, dsteps=2)          # graph: 2 D exchanges + 1 G exchange per step
+    hist = []
+    for s_ in range(3):
+        t.step(codes[lo:hi].cuda(), actions[lo:hi].cuda(), noise[s_, lo:hi].cuda())
+        hist.append(dp.reduce_loss_shares(t.losses()))
+    torch.cuda.synchronize()
+    torch.save({"g": t.g_flat.detach().cpu(), "d": t.d_flat.detach().cpu(), "hist": hist, "status": p2p.status(),
+                "d_steps": int(t.d_step[0]), "g_steps": int(t.g_step[0])}, os.path.join(out_dir, "d%d.pt" % rank))
+    del t
+    p2p.close()
+    dist.destroy_process_group()
+
+
+def test_p2p_two_discriminator_steps_per_iteration(tmp_path):
+    """discrim_steps_per_gen = 2 (train_gan.py:172): the repeat D step runs through k_d + k_wgrad + the exchanging
+    reduce kernel as well; D's exchange number advances twice per iteration, G's once."""
+    mp.spawn(_dsteps_main, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), "d%d.pt" % r)) for r in range(2)]
+    assert res[0]["status"] == 0 and res[1]["status"] == 0
+    assert res[0]["d_steps"] == 6 and res[0]["g_steps"] == 3
+    assert torch.equal(res[0]["g"], res[1]["g"]) and torch.equal(res[0]["d"], res[1]["d"])
+    assert res[0]["hist"] == res[1]["hist"]
+    codes, actions, noise = O.synthetic_batch(12, BATCH_GLOBAL, K, NZ, steps=3)
+    t = _make_trainer(codes.shape[0], codes.shape[0], None, dsteps=2)
+    t.step(codes.cuda(), actions.cuda(), noise[0].cuda())
+    want = t.losses()
+    got = res[0]["hist"][0]
+    assert abs(got[0] - want[0]) <= 1e-5 and abs(got[1] - want[1]) <= 1e-4
