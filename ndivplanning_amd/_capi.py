@@ -17,6 +17,7 @@ ACTION_DIM = 4
 MAX_NOISE_DIM = 16
 MAX_SAMPLES = 256
 ROW_PAD = 32
+EXPECTED_VERSION = 110          # NDP_VERSION of include/ndp.h this binding was written against
 
 _lib = None
 
@@ -115,6 +116,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if lib.ndp_version() != EXPECTED_VERSION:
+        raise NdpError("%s is version %d, this package needs %d: rebuild with `python -m ndivplanning_amd._build`"
+                       % (path, lib.ndp_version(), EXPECTED_VERSION))
     _lib = lib
     return lib
 
