@@ -139,7 +139,8 @@ def main():
         # gradient exchange: in-kernel peer-to-peer (hipIpc over xGMI) if it passes its self-check on
         # this node, RCCL all-reduce between the phases otherwise (NDP_DP_EXCHANGE=rccl|p2p forces one)
         if world > 1:
-            p2p, reduce_fn, exchange = dp.make_exchange(dev, world, log=lambda m_: print("[bench] " + m_, file=sys.stderr))
+            p2p, reduce_fn, exchange = dp.make_exchange(
+                dev, world, log=(lambda m_: print("[bench] " + m_, file=sys.stderr)) if rank == 0 else None)
         else:
             reduce_fn, exchange = dp.sum_all_reduce(), "rccl"
 
@@ -283,7 +284,8 @@ def main():
                    "rows_per_gpu": m, "global_batch": batch * world, "parallelism": "dp%d" % world,
                    "trajectories_per_sec": round(iters_per_s * batch * world, 1),
                    "hip_graph": hip_graph, "steps_per_graph_launch": spl if hip_graph else 0,
-                   "gradient_exchange": exchange, "replicas_bit_identical": replicas_identical, "last_losses": {"D": losses[0], "G": losses[1], "ndiv": losses[2]}},
+                   "gradient_exchange": exchange, "all_reduce_us": dict(dp.last_exchange_report) or None,
+                   "replicas_bit_identical": replicas_identical, "last_losses": {"D": losses[0], "G": losses[1], "ndiv": losses[2]}},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                      "traffic": PMC_HBM_BYTES_DEFAULT.get(dom) if (batch, k) == (64, 6) else None,

@@ -228,6 +228,39 @@ class P2PExchange:
         self.reset()
         return bool(flag.item() == 1)
 
+    def measure(self, n=83780, iters=40):
+        """(p2p_us, collective_us): average time of one all-reduce of n floats through this exchange and through
+        torch.distributed (RCCL), GPU-timed on this rank, maximum over ranks.  Collective; resets the region."""
+        with torch.cuda.device(self.device):
+            x = torch.ones(n, device=self.device)
+            out = torch.empty_like(x)
+            words = torch.arange(1, iters + 9, dtype=torch.int32, device=self.device).repeat_interleave(4).reshape(-1, 4)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            for i in range(8):                                   # warm-up
+                self.all_reduce(x, words[i], net=1, out=out)
+            self._barrier()
+            ev[0].record()
+            for i in range(8, 8 + iters):
+                self.all_reduce(x, words[i], net=1, out=out)
+            ev[1].record()
+            nccl = dist.get_backend(self.group) == "nccl"
+            y = x.clone() if nccl else x.cpu()
+            for _ in range(4):
+                dist.all_reduce(y, group=self.group)
+            self._barrier()
+            ev[2].record()
+            for _ in range(iters):
+                dist.all_reduce(y, group=self.group)
+            ev[3].record()
+            torch.cuda.synchronize(self.device)
+            t = torch.tensor([ev[0].elapsed_time(ev[1]), ev[2].elapsed_time(ev[3])], dtype=torch.float64)
+            t = t * 1e3 / iters
+            if nccl:
+                t = t.to(self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        self.reset()
+        return float(t[0]), float(t[1])
+
     def close(self):
         if self._region is None:
             return
@@ -241,10 +274,16 @@ class P2PExchange:
         self._region = None
 
 
+last_exchange_report = {}       # filled by make_exchange: measured all-reduce times on this node
+
+
 def make_exchange(device, world, log=None):
     """Pick the gradient exchange of a data-parallel run: the in-kernel peer-to-peer exchange when
     it passes its self-check on this node, torch.distributed's all-reduce (RCCL) otherwise.
-    NDP_DP_EXCHANGE=rccl|p2p forces one.  Returns (p2p_or_None, reduce_fn_or_None, name)."""
+    NDP_DP_EXCHANGE=rccl|p2p forces one.  Returns (p2p_or_None, reduce_fn_or_None, name).  In "auto" the
+    exchange is also timed against the collective (the figures go to `log`): the in-kernel exchange additionally
+    saves two kernels and the eager launches of the step, so it is kept unless it is slower by more than
+    NDP_P2P_MARGIN_US (default 15) per all-reduce."""
     if world <= 1:
         return None, None, "none"
     want = os.environ.get("NDP_DP_EXCHANGE", "auto")
@@ -253,6 +292,14 @@ def make_exchange(device, world, log=None):
         try:
             p2p = P2PExchange(device)
             good = p2p.self_check()
+            if good:
+                t_p2p, t_coll = p2p.measure()
+                last_exchange_report.update(p2p_us=round(t_p2p, 2), collective_us=round(t_coll, 2), floats=83780)
+                if log:
+                    log("all-reduce of 83,780 floats over %d ranks: peer-to-peer %.1f us, torch.distributed %.1f us"
+                        % (world, t_p2p, t_coll))
+                if want == "auto" and t_p2p > t_coll + float(os.environ.get("NDP_P2P_MARGIN_US", "15")):
+                    good = False
         except Exception as exc:                                 # noqa: BLE001
             good = False
             if log:
