@@ -274,6 +274,22 @@ int ndp_p2p_status(const ndp_p2p *p2p, int32_t *status_out);
 int ndp_p2p_all_reduce(const ndp_p2p *p2p, int net, const float *in, float *out, int64_t n,
                        const int32_t *step_word, void *stream);
 
+/* ------------------------------------------------------------ image encoder ---
+ * models.image_autoencoder.Encoder.forward in eval mode without gradient
+ * (image_autoencoder.py:35-49; train_gan.py:75-76 loads it, 152-153 calls it under
+ * .detach()): images [n,3,128,128] (NCHW, as the reference's loader delivers them) ->
+ * codes [n,128].  conv1 runs on the VALU (K = 27), conv2..conv6 as implicit GEMMs on the
+ * fp32 matrix pipe over NHWC activations kept in `workspace`.
+ * packed_params: ndp_encoder_param_floats() floats, BatchNorm (eval: running statistics,
+ * eps 1e-5) of conv1..conv3 folded into weights and biases:
+ *   conv1  w[27][64] with k = ci*9 + kh*3 + kw, then bias[64];
+ *   conv2..conv6  w[Cout][KH][KW][Cin], then bias[Cout]   (in this order, back to back).
+ * Images are processed in passes of at most 512; workspace: ndp_encoder_workspace_floats(n). */
+int64_t ndp_encoder_param_floats(void);
+int64_t ndp_encoder_workspace_floats(int64_t n_images);
+int ndp_encoder_forward(const float *packed_params, const float *images, int64_t n_images,
+                        float *codes, float *workspace, void *stream);
+
 /* ------------------------------------------------------------ measurement ---
  * Per-kernel timing for bench.py: while enabled (per host thread) every kernel
  * this library launches is bracketed by hipEvents recorded on the stream it is

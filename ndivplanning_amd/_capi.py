@@ -92,6 +92,9 @@ SIGNATURES = {
     "ndp_p2p_close": (c_int, [c_void_p]),
     "ndp_p2p_status": (c_int, [POINTER(P2P), POINTER(c_int32)]),
     "ndp_p2p_all_reduce": (c_int, [POINTER(P2P), c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "ndp_encoder_param_floats": (c_int64, []),
+    "ndp_encoder_workspace_floats": (c_int64, [c_int64]),
+    "ndp_encoder_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "ndp_timing_enable": (c_int, [c_int]),
     "ndp_timing_collect": (c_int, [ctypes.c_char_p, c_int, POINTER(c_float), POINTER(c_int32), c_int]),
 }

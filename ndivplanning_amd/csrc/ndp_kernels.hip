@@ -1502,3 +1502,4 @@ __global__ __launch_bounds__(kThreads) void k_philox(float* out, int64_t n, uint
 }  // namespace ndp
 
 #include "ndp_capi.inc"
+#include "ndp_encoder.inc"
