@@ -278,8 +278,8 @@ int ndp_p2p_all_reduce(const ndp_p2p *p2p, int net, const float *in, float *out,
  * models.image_autoencoder.Encoder.forward in eval mode without gradient
  * (image_autoencoder.py:35-49; train_gan.py:75-76 loads it, 152-153 calls it under
  * .detach()): images [n,3,128,128] (NCHW, as the reference's loader delivers them) ->
- * codes [n,128].  conv1 runs on the VALU (K = 27), conv2..conv6 as implicit GEMMs on the
- * fp32 matrix pipe over NHWC activations kept in `workspace`.
+ * codes [n,128].  All six layers are implicit GEMMs on the fp32 matrix pipe (conv1: K = 27
+ * padded to one 32-wide step) over NHWC activations kept in `workspace`.
  * packed_params: ndp_encoder_param_floats() floats, BatchNorm (eval: running statistics,
  * eps 1e-5) of conv1..conv3 folded into weights and biases:
  *   conv1  w[27][64] with k = ci*9 + kh*3 + kw, then bias[64];

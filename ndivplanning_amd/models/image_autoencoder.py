@@ -5,8 +5,8 @@ applied) + a 4x4 conv to 128 channels; 3x128x128 -> 128x1x1.
 
 On the GAN path it runs in eval mode under `no_grad` ahead of the step (train_gan.py:75-76,
 152-153): that case -- CUDA input, eval mode, no gradient wanted -- goes through the gfx950
-kernels of `csrc/ndp_encoder.inc` (`ndp_encoder_forward`: VALU conv1, implicit-GEMM conv2..6 on
-the fp32 matrix pipe, BatchNorm folded into the weights).  Training the autoencoder itself
+kernels of `csrc/ndp_encoder.inc` (`ndp_encoder_forward`: implicit-GEMM convolutions on the fp32
+matrix pipe, BatchNorm folded into the weights).  Training the autoencoder itself
 (train_autoencoder.py) is outside this repository's scope; a forward in training mode or with
 gradients keeps PyTorch's operators so that the class still behaves like an nn.Module there.
 The class also exists so that the reference's whole-module encoder pickles load."""
