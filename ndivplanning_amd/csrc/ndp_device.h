@@ -413,6 +413,9 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, size_t gld,
                                            const float* src, int ld) {
   constexpr int R = 16 * RT;
   constexpr int NV = R * W / 4;
+#ifdef NDP_EXP_NOSTORE     // diagnostic ablation: what the activation stores cost on the critical path
+  if (gld == 0x7fffffff)
+#endif
   for (int idx = threadIdx.x; idx < NV; idx += kThreads) {
     const int row = idx / (W / 4), k = 4 * (idx % (W / 4));
     *reinterpret_cast<f32x4*>(dst + (size_t)row * gld + k) =
