@@ -1410,42 +1410,40 @@ template <bool P2P>
 __global__ __launch_bounds__(kThreads) void k_reduce_adam(ReduceArgs a) {
   __shared__ float sh[8];
   const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  const bool live = p < a.n;
+  const bool upd = live && a.params != nullptr;
   float g = 0.f;
-  if (p < a.n) {
-    // fixed summation order (bitwise reproducible); 16 loads are issued before the first add so
-    // that a slab sum costs ~2 memory round trips instead of nchunks/4
+  // Everything this thread needs is requested before anything is consumed: the Adam operands, and up to 32 slab
+  // values at a time (one memory round trip for the 16..24 slabs of the small configurations).  The slabs are
+  // added in chunk order: bitwise reproducible.
+  float pv = 0.f, m = 0.f, v = 0.f, step_size = 0.f, bc2_sqrt = 1.f;
+  if (upd) {
+    pv = a.params[p]; m = a.exp_avg[p]; v = a.exp_avg_sq[p];
+    step_size = reinterpret_cast<const float*>(a.step)[1];
+    bc2_sqrt = reinterpret_cast<const float*>(a.step)[2];
+  }
+  if (live) {
     const float* sp = a.slabs + p;
-    int ch = 0;
-    for (; ch + 16 <= a.nchunks; ch += 16) {
-      float t[16];
+    for (int ch = 0; ch < a.nchunks; ch += 32) {
+      float t[32];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) t[u] = sp[(size_t)(ch + u) * a.slab_stride];
+      for (int u = 0; u < 32; ++u) t[u] = (ch + u < a.nchunks) ? sp[(size_t)(ch + u) * a.slab_stride] : 0.f;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) g += t[u];
-    }
-    {
-      float t[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) t[u] = (ch + u < a.nchunks) ? sp[(size_t)(ch + u) * a.slab_stride] : 0.f;
-#pragma unroll
-      for (int u = 0; u < 16; ++u) g += t[u];
+      for (int u = 0; u < 32; ++u) g += t[u];
     }
   }
-  if constexpr (P2P) g = p2p_sum(a.p2p, g, p, p < a.n, (uint32_t)a.step[0]);     // sum over ranks
-  if (p < a.n) {
-    if (a.grad != nullptr) a.grad[p] = g;
-    if (a.params != nullptr) {
-      const float step_size = reinterpret_cast<const float*>(a.step)[1];
-      const float bc2_sqrt = reinterpret_cast<const float*>(a.step)[2];
-      float pv = a.params[p], m = a.exp_avg[p], v = a.exp_avg_sq[p];
-      adam_update(pv, g, m, v, step_size, bc2_sqrt, a.beta1, a.beta2, a.eps);
-      a.params[p] = pv;
-      a.exp_avg[p] = m;
-      a.exp_avg_sq[p] = v;
-      if (a.pack.packed != nullptr) pack_store(a.pack, (int)p, pv);
-    }
+  if constexpr (P2P) g = p2p_sum(a.p2p, g, p, live, (uint32_t)a.step[0]);     // sum over ranks
+  if (live && a.grad != nullptr) a.grad[p] = g;
+  if (upd) {
+    adam_update(pv, g, m, v, step_size, bc2_sqrt, a.beta1, a.beta2, a.eps);
+    a.params[p] = pv;
+    a.exp_avg[p] = m;
+    a.exp_avg_sq[p] = v;
+    if (a.pack.packed != nullptr) pack_store(a.pack, (int)p, pv);
   }
-  if (blockIdx.x == 0) {
+  // the loss scalars are the LAST block's job: the launch has one block more than the parameters need, so
+  // this runs beside the parameter blocks instead of after one of them
+  if (blockIdx.x == gridDim.x - 1) {
     for (int t = 0; t < a.nloss; ++t) {
       const LossTerm lt = a.loss[t];
       float s = 0.f;
