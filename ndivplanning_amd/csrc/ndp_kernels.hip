@@ -1084,19 +1084,21 @@ struct WgradJob {
   // entry e = tile*seg_s + s pairs with code row (16*tile)/seg_k + s.  rows == 0: plain job.
   int rows, seg_s, seg_k;
   int seg_wrap;        // entries per pass when real and fake segment sums are kept apart (0: one set)
+  int nchunks;         // row chunks (= slabs) of THIS job, <= WgradArgs::nchunks: the full 64 x 64 jobs take more
 };
 constexpr int kMaxJobs = 28;
 struct WgradArgs {
   WgradJob job[kMaxJobs];
   int njobs;
   int rows;            // total rows (multiple of 16)
-  int rows_per_chunk;  // multiple of 16
   float* slabs;        // [nchunks][slab_stride]
   int64_t slab_stride;
   int32_t* bump;       // Adam state {int32 step; float step_size; float bc2_sqrt; pad} to advance, or null
   float lr, beta1, beta2;
-  int nchunks;
+  int nchunks;         // maximum over the jobs: grid and slab count
   NdivArgs nd;         // blocks njobs*nchunks.. : NDiv (cx <= 4, cz <= 2) riding in this launch; nd.n == 0: none
+  int net_is_g;        // host side only: kernel timing label
+  int nreg, reg_begin[4], reg_end[4];   // host side only: layers whose jobs are "light" (fewer chunks)
 };
 
 #ifdef NDP_STAMPS
@@ -1282,16 +1284,16 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
   }
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
   const int job_id = idx % a.njobs, chunk = xcd + 8 * (idx / a.njobs);
-  if (chunk >= a.nchunks) return;
   const WgradJob& jb = a.job[job_id];
+  if (chunk >= jb.nchunks) return;
   // a job's row space: all rows of the step (a.rows), or its own (segment-sum jobs)
   const int jrows = jb.rows != 0 ? jb.rows : a.rows;
-  const int jrpc = jb.rows != 0 ? (((jb.rows + a.nchunks - 1) / a.nchunks + 15) & ~15) : a.rows_per_chunk;
+  const int jrpc = ((jrows + jb.nchunks - 1) / jb.nchunks + 15) & ~15;
   const int rbeg = chunk * jrpc;
   int rend = rbeg + jrpc;
   rend = rend < jrows ? rend : jrows;
   float* slab = a.slabs + (size_t)chunk * a.slab_stride;
-  if (a.bump != nullptr && blockIdx.x == 0 && threadIdx.x == 0)   // block 0 = (chunk 0, job 0): always live
+  if (a.bump != nullptr && blockIdx.x == 0 && threadIdx.x == 0)   // block 0 = (chunk 0, job 0): always live (every job has >= 1 chunk)
     adam_advance(a.bump, a.lr, a.beta1, a.beta2);
   const int kind = jb.kind;   // uniform per workgroup
 #ifdef NDP_STAMPS
@@ -1388,6 +1390,8 @@ __device__ __forceinline__ float p2p_sum(const P2PArgs& x, float g, int64_t p, b
 
 struct ReduceArgs {
   const float* slabs; int nchunks; int64_t slab_stride; int64_t n;
+  // parameter ranges (whole layers) whose weight-gradient jobs wrote fewer slabs than nchunks
+  int nregions; int reg_begin[4], reg_end[4], reg_slabs[4];
   P2PArgs p2p;
   float* grad;                         // [n] or null
   float *params, *exp_avg, *exp_avg_sq;   // Adam (params null -> no update)
@@ -1424,10 +1428,13 @@ __global__ __launch_bounds__(kThreads) void k_reduce_adam(ReduceArgs a) {
   }
   if (live) {
     const float* sp = a.slabs + p;
-    for (int ch = 0; ch < a.nchunks; ch += 32) {
+    int nch = a.nchunks;
+    for (int r = 0; r < a.nregions; ++r)
+      if (p >= a.reg_begin[r] && p < a.reg_end[r]) nch = a.reg_slabs[r];
+    for (int ch = 0; ch < nch; ch += 32) {
       float t[32];
 #pragma unroll
-      for (int u = 0; u < 32; ++u) t[u] = (ch + u < a.nchunks) ? sp[(size_t)(ch + u) * a.slab_stride] : 0.f;
+      for (int u = 0; u < 32; ++u) t[u] = (ch + u < nch) ? sp[(size_t)(ch + u) * a.slab_stride] : 0.f;
 #pragma unroll
       for (int u = 0; u < 32; ++u) g += t[u];
     }

@@ -69,6 +69,19 @@ elif which == "wa":
     # D weight gradient inside the real phase A (2 passes): k_wgrad is the last stamping kernel
     nch = min(512 // 19, 2 * mpad // 64, 64)
     report("k_wgrad[D, 2 pass] [0 setup,1 main loop,2 lds write,3 reduce+store]", lambda: tr._phase_a(True), 4, 19 * nch)
+    # per job: workgroup b -> xcd = b & 7, idx = b >> 3, job = idx % 19, chunk = xcd + 8 * (idx // 19)
+    nchunks = int(os.environ.get("CH", 24))
+    nblk = 8 * ((nchunks + 7) // 8) * 19
+    w = stamps.cpu().numpy().reshape(-1, 16, 2)[:nblk][:, :, 1].astype(np.float64)
+    t0 = w[w[:, 0] > 0, 0].min()
+    names = ["fc1c0", "fc1c1", "fc1c2", "fc1c3", "fc1act", "fc2a", "fc2b"] + ["fc3_%d" % i for i in range(8)] + ["fc4_%d" % i for i in range(4)]
+    for job in range(19):
+        rows = [b for b in range(nblk) if (b >> 3) % 19 == job and w[b, 0] > 0]
+        st, en = w[rows, 0] - t0, w[rows, 4] - t0
+        main = w[rows, 2] - w[rows, 1]
+        print("   job %2d %-7s: start %.2f..%.2f us, main loop median %.2f max %.2f, end median %.2f max %.2f"
+              % (job, names[job], st.min() / 100, st.max() / 100, np.median(main) / 100, main.max() / 100,
+                 np.median(en) / 100, en.max() / 100))
 elif which == "wb":
     nch = min(512 // 26, mpad // 64, 64)
     tr._phase_a(True)
