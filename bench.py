@@ -35,12 +35,12 @@ import torch  # noqa: E402
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per launch of the step's kernels at the DEFAULT workload (B=64, K=6), from separate
-# `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (profiles/r01_v5_pmc_hbm.csv), with the
+# `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (profiles/r01_v7_pmc_hbm.csv), with the
 # gfx950 correction of MI355X_MICROARCH.md section HBM: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
 # bench.py cannot read PMC counters itself; the figure is reported only for the workload it was
 # measured on.
-PMC_HBM_BYTES_DEFAULT = {"k_phase_a": 33658287, "k_phase_b": 18604553, "k_wgrad[D]": 30853773,
-                         "k_wgrad[G]": 25787329}
+PMC_HBM_BYTES_DEFAULT = {"k_phase_a": 33656488, "k_phase_b": 18603529, "k_wgrad[D]": 34154522,
+                         "k_wgrad[G]": 21469747}
 
 # algorithmic MACs per M-row of each kernel (629,760 per row per step)
 G_FWD = 128 * 258 + 64 * 128 + 128 * 64 + 256 * 128 + 4 * 256           # 83,200
@@ -289,7 +289,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                      "traffic": PMC_HBM_BYTES_DEFAULT.get(dom) if (batch, k) == (64, 6) else None,
-                     "traffic_source": "profiles/r01_v5_pmc_hbm.csv (rocprofv3 --pmc, bytes per launch)",
+                     "traffic_source": "profiles/r01_v7_pmc_hbm.csv (rocprofv3 --pmc, bytes per launch)",
                      "algorithmic_flops_per_launch": dom_flops,
                      "whole_step": {"flops": step_flops,
                                     "tflops": round(step_flops * iters_per_s / 1e12, 3),
