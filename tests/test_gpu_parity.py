@@ -386,7 +386,8 @@ def test_multi_step_graph_is_bitwise_single_steps():
 
 # (64, 6): config 2, phase A with paired real tiles (168 tiles); (52, 6): the same form with a ragged last tile
 # (M = 2184, 138 tiles); (25, 6): one real tile per helper workgroup (66 tiles); (72, 6): stacked passes (189 tiles)
-@pytest.mark.parametrize("batch,k", [(64, 6), (128, 32), (5, 7), (52, 6), (25, 6), (72, 6)])
+# (128, 6): k_wgrad[G] with per-job chunk counts beside k_wgrad[D] with uniform ones (>= 16,384 rows)
+@pytest.mark.parametrize("batch,k", [(64, 6), (128, 32), (5, 7), (52, 6), (25, 6), (72, 6), (128, 6)])
 def test_free_running_vs_oracle(batch, k):
     """Free-running (no forcing) for 3 steps at BASELINE shapes: BCE losses stay within
     1e-4; NDiv within the free-running bound (Adam amplifies summation-order noise, see
