@@ -3,8 +3,8 @@
 (BatchNorm only after the first three; conv4_bn / conv5_bn exist as attributes but are not
 applied) + a 4x4 conv to 128 channels; 3x128x128 -> 128x1x1.
 
-On the GAN path it runs in eval mode under `no_grad` ahead of the step (train_gan.py:75-76,
-152-153): that case -- CUDA input, eval mode, no gradient wanted -- goes through the gfx950
+On the GAN path it runs in eval mode ahead of the step and its output is detached (train_gan.py:75-76,
+152-153): that case -- CUDA input, eval mode, input without grad -- goes through the gfx950
 kernels of `csrc/ndp_encoder.inc` (`ndp_encoder_forward`: implicit-GEMM convolutions on the fp32
 matrix pipe, BatchNorm folded into the weights).  Training the autoencoder itself
 (train_autoencoder.py) is outside this repository's scope; a forward in training mode or with
@@ -37,8 +37,11 @@ class Encoder(nn.Module):
             normal_init(self._modules[name], mean, std)
 
     def forward(self, x):
-        wants_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if x.is_cuda and not self.training and not wants_grad:
+        # Every caller in the reference detaches the codes at once (train_gan.py:152-153, control_evaluation.py:110-111,
+        # mpc_eval.py:139-140) with grad mode on and the loaded parameters still requiring grad: an eval-mode forward
+        # is therefore NOT differentiable with respect to the encoder's parameters here; only an input that itself
+        # requires grad (or training mode) selects the PyTorch operators.
+        if x.is_cuda and not self.training and not (torch.is_grad_enabled() and x.requires_grad):
             return _encoder_forward_hip(self, x)
         return self._forward_torch(x)
 

@@ -57,6 +57,10 @@ def test_eval_no_grad_cuda_is_the_hip_path_and_everything_else_is_not():
     with torch.no_grad():
         enc(x)                                    # still enabled: launches are recorded
     assert _capi.timing_collect()
+    out = enc(x)                                  # the reference's pattern: grad mode on, output detached by the caller
+    assert _capi.timing_collect() and not out.requires_grad
+    enc(x.clone().requires_grad_(True))           # an input that wants a gradient: PyTorch operators
+    assert not _capi.timing_collect()
     enc.train()
     with torch.no_grad():
         enc(x)                                    # training mode: PyTorch operators (batch statistics), no HIP launch
