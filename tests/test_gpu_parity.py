@@ -599,3 +599,26 @@ def test_trainer_sees_parameter_writes_made_through_torch():
     dec2 = dec.to("cpu").to(DEV)                          # storages replaced: the trainer re-binds
     tr.step(codes.to(DEV), actions.to(DEV), noise[0].to(DEV))
     assert dec2.flat_parameters().data_ptr() == tr.g_flat.data_ptr()
+
+
+def test_generator_inference_as_the_evaluation_scripts_call_it(tmp_path):
+    """control_evaluation.py:111-121 / mpc_eval.py:135-149: a decoder restored from its whole-module pickle
+    (train_gan.py:254-266 writes it, control_evaluation.py:175-176 loads it), called with grad mode ON on
+    `rollouts x K` rows built by diverse_sampling -- cat(code.expand(K), noise) with two trailing singleton dims,
+    viewed back to [M, 258] -- and reshaped to [rollouts, K, 4]."""
+    import os
+    import models.gan  # noqa: F401  -- the reference's module name (root shim): pickles then record models.gan.Decoder
+    g, d = O.init_params(4, 2)
+    dec, _ = _load_modules(g, d, 2)
+    path = os.path.join(str(tmp_path), "gan_decoder_9.pt")
+    torch.save(dec, path)
+    gen = torch.load(path, weights_only=False)                  # our own file: a whole-module pickle, as the reference's
+    assert type(gen).__module__ == "models.gan" and type(gen).__name__ == "Decoder"
+    rollouts, k = 5, 6
+    codes = torch.randn(rollouts, 256, generator=torch.Generator().manual_seed(1))
+    noise = torch.rand(rollouts, k, 2, generator=torch.Generator().manual_seed(2))
+    diverse = torch.cat([codes[:, None].expand(-1, k, -1), noise], dim=2)[..., None, None].to(DEV)   # train_gan.py:42-47
+    out = gen(diverse.view(-1, diverse.size(2))).view(rollouts, -1, 4)
+    ref = O.g_forward(g, torch.cat([codes[:, None].expand(-1, k, -1), noise], dim=2).reshape(-1, 258))
+    ref = ref[-1] if isinstance(ref, (tuple, list)) else ref
+    _close(out.reshape(-1, 4), ref.reshape(-1, 4), 1e-4, "action_hat (inference)")
