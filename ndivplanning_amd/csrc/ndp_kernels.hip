@@ -1431,12 +1431,15 @@ __global__ __launch_bounds__(kThreads) void k_reduce_adam(ReduceArgs a) {
     int nch = a.nchunks;
     for (int r = 0; r < a.nregions; ++r)
       if (p >= a.reg_begin[r] && p < a.reg_end[r]) nch = a.reg_slabs[r];
-    for (int ch = 0; ch < nch; ch += 32) {
-      float t[32];
+    // (the exchanging variant keeps 16 in flight: its waves hold their registers while they wait for the peers,
+    // and with several ranks sharing one GPU in the tests a fat waiting kernel can keep a peer's kernels off the CUs)
+    constexpr int NB = P2P ? 16 : 32;
+    for (int ch = 0; ch < nch; ch += NB) {
+      float t[NB];
 #pragma unroll
-      for (int u = 0; u < 32; ++u) t[u] = (ch + u < nch) ? sp[(size_t)(ch + u) * a.slab_stride] : 0.f;
+      for (int u = 0; u < NB; ++u) t[u] = (ch + u < nch) ? sp[(size_t)(ch + u) * a.slab_stride] : 0.f;
 #pragma unroll
-      for (int u = 0; u < 32; ++u) g += t[u];
+      for (int u = 0; u < NB; ++u) g += t[u];
     }
   }
   if constexpr (P2P) g = p2p_sum(a.p2p, g, p, live, (uint32_t)a.step[0]);     // sum over ranks

@@ -130,30 +130,56 @@ class P2PExchange:
         import ctypes
         self._mapped = []
         self._region = ctypes.c_void_p()
+        # Every rank runs the SAME sequence of collectives whatever fails locally (a rank that raised before a
+        # collective would leave the others waiting in it): local errors are carried through and raised together.
+        err = None
+        handle = ctypes.create_string_buffer(_capi.P2P_HANDLE_BYTES)
         with torch.cuda.device(self.device):
-            _capi.check(self.lib.ndp_p2p_region_alloc(ctypes.byref(self._region)), "ndp_p2p_region_alloc")
-            handle = ctypes.create_string_buffer(_capi.P2P_HANDLE_BYTES)
-            _capi.check(self.lib.ndp_p2p_export(self._region, handle), "ndp_p2p_export")
+            try:
+                _capi.check(self.lib.ndp_p2p_region_alloc(ctypes.byref(self._region)), "ndp_p2p_region_alloc")
+                _capi.check(self.lib.ndp_p2p_export(self._region, handle), "ndp_p2p_export")
+            except Exception as exc:                                   # noqa: BLE001
+                err = repr(exc)
             handles = [None] * self.world
-            dist.all_gather_object(handles, (self.rank, os.getpid(), handle.raw), group=group)
+            dist.all_gather_object(handles, (self.rank, os.getpid(), handle.raw, err), group=group)
             self.struct = _capi.P2P()
             self.struct.world, self.struct.rank, self.struct.timeout_ms = self.world, self.rank, int(timeout_ms)
-            for r, (src, pid, raw) in enumerate(handles):
-                if src != r:
-                    raise RuntimeError("peer-to-peer exchange: handle list out of rank order")
-                if r == self.rank:
-                    self.struct.region[r] = self._region.value
-                    continue
-                if pid == os.getpid():
-                    raise RuntimeError("peer-to-peer exchange needs one PROCESS per rank (hipIpc)")
-                mapped = ctypes.c_void_p()
-                _capi.check(self.lib.ndp_p2p_open(ctypes.create_string_buffer(raw, len(raw)), ctypes.byref(mapped)),
-                            "ndp_p2p_open(rank %d)" % r)
-                self._mapped.append(mapped)
-                self.struct.region[r] = mapped.value
+            if err is None and all(h[3] is None for h in handles):
+                try:
+                    for r, (src, pid, raw, _e) in enumerate(handles):
+                        if src != r:
+                            raise RuntimeError("peer-to-peer exchange: handle list out of rank order")
+                        if r == self.rank:
+                            self.struct.region[r] = self._region.value
+                            continue
+                        if pid == os.getpid():
+                            raise RuntimeError("peer-to-peer exchange needs one PROCESS per rank (hipIpc)")
+                        mapped = ctypes.c_void_p()
+                        _capi.check(self.lib.ndp_p2p_open(ctypes.create_string_buffer(raw, len(raw)), ctypes.byref(mapped)),
+                                    "ndp_p2p_open(rank %d)" % r)
+                        self._mapped.append(mapped)
+                        self.struct.region[r] = mapped.value
+                except Exception as exc:                               # noqa: BLE001
+                    err = repr(exc)
+            else:
+                err = err or "a peer failed: %s" % next(h[3] for h in handles if h[3] is not None)
+            errs = [None] * self.world
+            dist.all_gather_object(errs, err, group=group)
+        if any(e is not None for e in errs):
+            self._release_local()
+            raise RuntimeError("peer-to-peer exchange could not be set up: %s" % next(e for e in errs if e is not None))
         self._barrier()
 
     # ---- helpers
+    def _release_local(self):
+        with torch.cuda.device(self.device):
+            for m in self._mapped:
+                self.lib.ndp_p2p_close(m)
+            self._mapped = []
+            if self._region is not None and self._region.value:
+                self.lib.ndp_p2p_region_free(self._region)
+        self._region = None
+
     def _barrier(self):
         torch.cuda.synchronize(self.device)
         dist.barrier(group=self.group)

@@ -16,7 +16,7 @@ from oracle import gan_oracle as O
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BATCH_GLOBAL, K, NZ, STEPS = 8, 6, 2, 5          # FLAT_global = 56
+BATCH_GLOBAL, K, NZ, STEPS = 12, 6, 2, 5         # FLAT_global = 84: splits over 2 and 3 ranks
 
 
 def _free_port():
@@ -90,7 +90,10 @@ def _rank_main(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+# (3, not 4: every rank's kernels must be resident together for the in-kernel hand-shake, and four processes' worth of
+# 253-register phase-A waves plus three waiting reduce kernels do not always fit ONE GPU -- seen as a bounded-wait
+# time-out, 1 run in 3; on a node every rank has a GPU of its own)
+@pytest.mark.parametrize("world", [2, 3])
 def test_p2p_exchange_ranks_as_processes_on_one_gpu(tmp_path, world):
     mp.spawn(_rank_main, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     res = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
