@@ -11,36 +11,55 @@ Inputs (codes, actions) are resident in HBM; the K noise samples are drawn per s
 device inside the timed region; nothing is skipped (both Adam updates, all three losses).
 
 N > 1 is weak scaling: every rank trains its own 64-trajectory shard of a global batch of
-64*N (gradients summed by one RCCL all-reduce per network per step), so `value` counts
-batch-64 steps: N * iterations/s.
+64*N (gradients summed over ranks once per network per step), so `value` counts batch-64
+steps: N * iterations/s.
 
-Rank 0 prints one JSON line (contract in the task statement) with two extra objects:
+Timing: W warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides,
+maximum over ranks.  When K steps take less than ~50 ms the bracket is repeated R times back to
+back and the MEDIAN repetition is reported (`config.repeats`, all repetitions in
+`config.repeat_ms_per_step`): a 20-step run is 1.9 ms of GPU time, one sample of which says little.
+
+Rank 0 prints one JSON line (contract in the task statement) with extra objects:
   roofline     the dominant kernel of the step vs the fp32-MFMA peak (157.3 TFLOP/s):
                algorithmic FLOPs of that kernel per launch / its average duration, measured
                with HIP events on the launch stream (ndp_timing_*), plus every kernel's share;
-  cpu_baseline the oracle's restated reference loop (torch CPU fp32) timed on this host.
+  cpu_baseline the oracle's restated reference loop (torch CPU fp32) timed on this host (N = 1);
+  h2d_per_launch   the same workload with a FRESH batch uploaded from pinned host memory for every
+               step (the reference uploads per step, train_gan.py:119-124), overlapped with the
+               previous graph launch (N = 1);
+  config4      BASELINE configs[3]: image-conditioned step at B = 128 -- frozen encoder over the
+               1,024 unique frames + the fused step at M = 5,376 (N = 1);
+  large_m      the config-5 per-GPU shard (B = 128, K = 32) and B = 1,024 / K = 6: whole-step
+               fraction of the fp32-MFMA peak where the matrix pipe, not launch latency, is the story;
+  strong_config3, config5_shard   (N > 1) global batch 256 split over the ranks, and the config-5 shard
+               per rank, with the gradient exchange that ran and both exchanges timed.
 """
 import argparse
 import json
+import math
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# read by HSA when the runtime initialises (first torch.cuda call): dmabuf IPC for hipIpc / RCCL
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per launch of the step's kernels at the DEFAULT workload (B=64, K=6), from separate
-# `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (profiles/r01_v7_pmc_hbm.csv), with the
+# `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (profiles/*_pmc_hbm.csv), with the
 # gfx950 correction of MI355X_MICROARCH.md section HBM: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
 # bench.py cannot read PMC counters itself; the figure is reported only for the workload it was
 # measured on.
 PMC_HBM_BYTES_DEFAULT = {"k_phase_a": 33656488, "k_phase_b": 18603529, "k_wgrad[D]": 34154522,
                          "k_wgrad[G]": 21469747}
+PMC_SOURCE = "profiles/r01_v7_pmc_hbm.csv (rocprofv3 --pmc, bytes per launch)"
 
 # algorithmic MACs per M-row of each kernel (SURVEY.md section 8d: 629,760 per row per step)
 G_FWD = 128 * 258 + 64 * 128 + 128 * 64 + 256 * 128 + 4 * 256           # 83,200
@@ -53,10 +72,13 @@ KERNEL_MACS_PER_ROW = {
     "k_phase_b": D_FWD + D_DGRAD + 4 * 64 + G_DGRAD,     # D' forward/backward to action_hat + G backward data path
     "k_wgrad[G]": G_FWD,
 }
-assert sum(KERNEL_MACS_PER_ROW.values()) == 629760
+MACS_PER_ROW_STEP = 629760
+assert sum(KERNEL_MACS_PER_ROW.values()) == MACS_PER_ROW_STEP
 # kernels of the non-fused entry points (repeat D steps, module API); not part of the default step
 KERNEL_MACS_PER_ROW.update({"k_g_fwd": G_FWD, "k_d[2 pass fwd+bwd]": 2 * (D_FWD + D_DGRAD),
                             "k_d[fwd+bwd]": D_FWD + D_DGRAD + 4 * 64, "k_g_bwd": G_DGRAD})
+ENCODER_FLOP_PER_IMAGE = 622.3e6                          # SURVEY.md section 8d (311.2 M MAC)
+TRAJ, NZ = 8, 2
 
 
 def parse_args():
@@ -68,11 +90,14 @@ def parse_args():
     ap.add_argument("--num-sample", type=int, default=6)
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a HIP graph")
     ap.add_argument("--steps-per-launch", type=int, default=16,
-                    help="iterations captured per HIP graph (single GPU; each iteration has its own input slot)")
+                    help="iterations captured per HIP graph (each iteration has its own input slot)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (profiling runs)")
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel code path (non-fused Adam + RCCL all-reduce) even with one rank")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--min-timed-ms", type=float, default=50.0,
+                    help="repeat the K-step bracket until about this much GPU time has been sampled; report the median")
     return ap.parse_args()
 
 
@@ -86,6 +111,12 @@ def cpu_baseline(batch, k, nz, seconds):
     # torch's default (= all hardware threads) oversubscribes these small GEMMs badly; probe a
     # few thread counts for ~1 s each and report the best one -- the fair baseline
     default_threads = torch.get_num_threads()
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False) or default_threads
+        logical = psutil.cpu_count(logical=True) or default_threads
+    except Exception:                                     # noqa: BLE001
+        physical = logical = os.cpu_count() or default_threads
     best = (0.0, default_threads)
     for cand in sorted({1, 4, 8, 16, 32, default_threads}):
         if cand > default_threads:
@@ -110,138 +141,146 @@ def cpu_baseline(batch, k, nz, seconds):
         dt = time.perf_counter() - t0
         if dt >= seconds or n >= 5000:
             break
-    return {"value": round(n / dt, 3), "unit": "steps/s", "cores": threads, "kind": "port",
-            "sample": "%d steps of the same B=%d,K=%d codes-mode workload in %.1f s (torch %s CPU fp32; best of "
-                      "{1,4,8,16,32,%d} threads = %d)" % (n, batch, k, dt, torch.__version__, default_threads, threads)}
+    torch.set_num_threads(default_threads)
+    return {"value": round(n / dt, 3), "unit": "steps/s", "cores": physical, "threads": threads,
+            "logical_cpus": logical, "kind": "port",
+            "sample": "%d steps of the same B=%d,K=%d codes-mode workload in %.1f s (torch %s CPU fp32; host has %d "
+                      "physical cores / %d hardware threads; best of {1,4,8,16,32,%d} torch threads = %d -- more "
+                      "threads are slower on these small GEMMs)"
+                      % (n, batch, k, dt, torch.__version__, physical, logical, default_threads, threads)}
 
 
-def main():
-    args = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("NDP_BENCH_ONE_GPU") == "1":
-        # rehearsal of the N > 1 path on a one-GPU box: all ranks share cuda:0 (needs NDP_DIST_BACKEND=gloo,
-        # RCCL refuses two ranks on one device); the number it prints is not a measurement
-        local_rank = 0
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
+class Bench:
+    """One process' view of the run: rank, device, the gradient exchange, the seeded networks."""
+
+    def __init__(self, args):
+        self.args = args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if os.environ.get("NDP_BENCH_ONE_GPU") == "1":
+            # rehearsal of the N > 1 path on a one-GPU box: all ranks share cuda:0 (needs NDP_DIST_BACKEND=gloo,
+            # RCCL refuses two ranks on one device); the number it prints is not a measurement
+            local_rank = 0
+        if args.gpus != self.world and self.world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs a torch.distributed.run launch with that many ranks" % args.gpus)
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path exists)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path exists)"
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+        import torch.distributed as dist
+        from ndivplanning_amd import dp
+        self.dist, self.dp = dist, dp
+        self.p2p, self.reduce_fn, self.exchange = None, None, "none"
+        if self.world > 1 or args.force_dp:
+            dp.init_process_group(self.dev, force=args.force_dp)     # RCCL; keeps its banner off stdout
+            # gradient exchange: in-kernel peer-to-peer (hipIpc over xGMI) if it passes its self-check on
+            # this node, RCCL all-reduce between the phases otherwise (NDP_DP_EXCHANGE=rccl|p2p forces one)
+            if self.world > 1:
+                self.p2p, self.reduce_fn, self.exchange = dp.make_exchange(self.dev, self.world, log=self.log)
+            else:
+                self.reduce_fn, self.exchange = dp.sum_all_reduce(), "rccl"
+        from oracle import gan_oracle as O   # inputs + the step-0 parity figure + cpu_baseline only
+        self.O = O
+        self.g0, self.d0 = O.init_params(0, NZ)
 
-    import torch.distributed as dist
-    from ndivplanning_amd import dp
-    reduce_fn, p2p, exchange = None, None, "none"
-    if world > 1 or args.force_dp:
-        dp.init_process_group(dev, force=args.force_dp)     # RCCL; keeps its banner off stdout
-        # gradient exchange: in-kernel peer-to-peer (hipIpc over xGMI) if it passes its self-check on
-        # this node, RCCL all-reduce between the phases otherwise (NDP_DP_EXCHANGE=rccl|p2p forces one)
-        if world > 1:
-            p2p, reduce_fn, exchange = dp.make_exchange(
-                dev, world, log=(lambda m_: print("[bench] " + m_, file=sys.stderr)) if rank == 0 else None)
-        else:
-            reduce_fn, exchange = dp.sum_all_reduce(), "rccl"
+    def log(self, msg):
+        if self.rank == 0:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
 
-    from ndivplanning_amd import _capi
-    from ndivplanning_amd.models.gan import Decoder, Discriminator
-    from ndivplanning_amd.trainer import GanTrainer
-    from oracle import gan_oracle as O   # inputs + the step-0 parity figure + cpu_baseline only
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        torch.cuda.synchronize(self.dev)
 
-    batch, k, nz, traj = args.batch, args.num_sample, 2, 8
-    flat = batch * (traj - 1)
-    m = flat * k
-    g, d = O.init_params(0, nz)
-    dec, dis = Decoder(nz), Discriminator()
-    dec.load_state_dict(g)
-    dis.load_state_dict(d)
-    dec, dis = dec.to(dev), dis.to(dev)
-    codes, actions, noise = O.synthetic_batch(1000 + rank, batch, k, nz, steps=1)
-    spl = args.steps_per_launch if (reduce_fn is None and not args.no_graph) else 1
+    def max_over_ranks(self, seconds):
+        if self.world == 1:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
 
-    def make_trainer():
-        dec.load_state_dict(g)
-        dis.load_state_dict(d)
-        return GanTrainer(dec, dis, flat=flat, num_sample=k, flat_global=flat * world, reduce_fn=reduce_fn, p2p=p2p,
-                          use_graph=not args.no_graph, noise_seed=rank, steps_per_launch=spl)
-    tr = make_trainer()
+    def make_trainer(self, batch, k, global_flat, spl, p2p, reduce_fn, use_graph=True):
+        from ndivplanning_amd.models.gan import Decoder, Discriminator
+        from ndivplanning_amd.trainer import GanTrainer
+        dec, dis = Decoder(NZ), Discriminator()
+        dec.load_state_dict(self.g0)
+        dis.load_state_dict(self.d0)
+        dec, dis = dec.to(self.dev), dis.to(self.dev)
+        if p2p is not None:
+            p2p.reset()                # a new trainer counts its exchanges from 1 again: flags must be zero
+        return GanTrainer(dec, dis, flat=batch * (TRAJ - 1), num_sample=k, flat_global=global_flat, reduce_fn=reduce_fn,
+                          p2p=p2p, use_graph=use_graph, noise_seed=self.rank, steps_per_launch=spl)
 
-    # step-0 parity figure (outside the timed region): NDiv / losses vs the oracle on rank 0's shard
-    parity = None
-    if world == 1:
-        ref = O.StepMath({n_: v.clone() for n_, v in g.items()}, {n_: v.clone() for n_, v in d.items()})
-        out = ref.step(codes, actions, noise[0])
-        tr.step(codes.to(dev), actions.to(dev), noise[0].to(dev))
-        dl, gl, pd = tr.losses()
-        parity = {"ndiv_rel_err": abs(pd - out["pair_div"].item()) / max(1.0, abs(out["pair_div"].item())),
-                  "d_loss_abs_err": abs(dl - out["d_loss"].item()), "g_loss_abs_err": abs(gl - out["g_loss"].item()),
-                  "action_hat_max_abs_err": (tr.action_hat[:m].cpu() - out["action_hat"]).abs().max().item()}
-
-    def fill_slots():
-        # every input slot holds its own resident synthetic batch
-        tr.codes.copy_(codes)
-        tr.actions.copy_(actions)
-        for slot in range(1, spl):
-            c_, a_, _ = O.synthetic_batch(2000 + 17 * slot + rank, batch, k, nz, steps=1)
+    def fill_slots(self, tr, batch, k, seed0=2000):
+        for slot in range(tr.nslots):
+            c_, a_, _ = self.O.synthetic_batch(seed0 + 17 * slot + self.rank, batch, k, NZ, steps=1)
             tr.codes_slots[slot].copy_(c_)
             tr.actions_slots[slot].copy_(a_)
-    fill_slots()
 
-    def run_steps(n):
-        done = 0
+    @staticmethod
+    def run_steps(tr, n, stepper=None):
+        spl, done = tr.nslots, 0
+        many = stepper or tr.step_many
         while spl > 1 and n - done >= spl:
-            tr.step_many()             # spl iterations, one graph replay
+            many()                     # spl iterations, one graph replay
             done += spl
         for _ in range(n - done):
             tr.step()                  # device noise, resident inputs
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+    def timed(self, tr, steps, warmup, stepper=None):
+        """Warm up, then R x (barrier, EXACTLY `steps` steps, barrier), maximum over ranks per repetition;
+        returns (median seconds per repetition, [seconds per repetition])."""
+        self.barrier()
+        self.run_steps(tr, max(warmup, 1), stepper)
+        self.run_steps(tr, tr.nslots + 1, stepper)                        # both graphs exist before timing
+        self.barrier()
+        reps, total = [], 1
+        want = self.args.min_timed_ms * 1e-3
+        while True:
+            self.barrier()
+            t0 = time.perf_counter()
+            self.run_steps(tr, steps, stepper)
+            self.barrier()
+            reps.append(self.max_over_ranks(time.perf_counter() - t0))
+            if len(reps) == 1 and reps[0] < want:
+                # every rank computes the same count from the max-reduced first repetition; odd, so that the
+                # median is a measured repetition
+                total = min(25, max(3, int(math.ceil(want / max(reps[0], 1e-6))))) | 1
+            if len(reps) >= total:
+                break
+        return statistics.median(reps), reps
 
-    barrier()
-    run_steps(args.warmup)
-    if p2p is not None:
-        # a wait that timed out during warm-up (status word) means the exchange does not work on this
-        # node although its self-check passed: fall back to the RCCL path rather than time garbage
-        bad = torch.tensor([p2p.status()], dtype=torch.int32, device=dev)
-        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-        if int(bad.item()) != 0:
-            print("[bench] peer-to-peer exchange timed out in warm-up; falling back to RCCL", file=sys.stderr)
-            del tr
-            p2p.close()
-            p2p, reduce_fn, exchange, spl = None, dp.sum_all_reduce(), "rccl (p2p timed out in warm-up)", 1
-            tr = make_trainer()
-            fill_slots()
-            barrier()
-            run_steps(args.warmup)
-    run_steps(spl + 1)                 # make sure both graphs exist before timing
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    losses = tr.losses()
-    hip_graph = bool(tr.use_graph)
 
-    # per-kernel durations: HIP events around every launch, eager launches of the same step
-    # (every rank steps -- the exchange needs all of them -- rank 0 records)
+def step_flops(m):
+    return 2.0 * MACS_PER_ROW_STEP * m
+
+
+def workload_summary(batch, k, world, sec, steps, reps, extra=None):
+    m = batch * (TRAJ - 1) * k
+    iters = steps / sec
+    out = {"batch_per_gpu": batch, "num_sample": k, "rows_per_gpu": m, "global_batch": batch * world,
+           "ms_per_step": round(1e3 * sec / steps, 5), "iterations_per_sec": round(iters, 2),
+           "trajectories_per_sec": round(iters * batch * world, 1), "repeats": len(reps),
+           "whole_step_tflops_per_gpu": round(step_flops(m) * iters / 1e12, 3),
+           "whole_step_frac_of_fp32_mfma_peak": round(step_flops(m) * iters / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
+    if extra:
+        out.update(extra)
+    return out
+
+
+def kernel_table(b, tr, m, reps=50):
+    """Per-kernel durations: HIP events around every launch, eager launches of the same step
+    (every rank steps -- the exchange needs all of them -- rank 0 records)."""
+    from ndivplanning_amd import _capi
     kernels = {}
     saved = tr.use_graph
     tr.use_graph = False
-    if rank == 0:
+    if b.rank == 0:
         _capi.timing_enable(True)
-    reps = 50
     for _ in range(reps):
         tr.step()
-    torch.cuda.synchronize(dev)
-    if rank == 0:
+    torch.cuda.synchronize(b.dev)
+    if b.rank == 0:
         timed = _capi.timing_collect()
         _capi.timing_enable(False)
         for name, (ms, cnt) in timed.items():
@@ -250,6 +289,150 @@ def main():
             kernels[name] = {"avg_us": round(us, 3), "launches_per_step": cnt / reps,
                              "tflops": round(2.0 * macs * m / (us * 1e-6) / 1e12, 3) if macs else None}
     tr.use_graph = saved
+    return kernels
+
+
+def large_m_point(b, batch, k, steps):
+    """A large-M single-GPU workload with its per-kernel table (whole-step fraction of the MFMA peak)."""
+    tr = b.make_trainer(batch, k, batch * (TRAJ - 1), 4, None, None)
+    b.fill_slots(tr, batch, k, seed0=5000)
+    sec, reps = b.timed(tr, steps, max(steps // 4, 8))
+    m = batch * (TRAJ - 1) * k
+    out = workload_summary(batch, k, 1, sec, steps, reps)
+    out["kernels"] = kernel_table(b, tr, m, reps=10)
+    del tr
+    torch.cuda.empty_cache()
+    return out
+
+
+def config4_point(b, steps):
+    """BASELINE configs[3]: image-conditioned generator, batch = 128, one GPU.  The reference encodes the current and the
+    target frame of every FLAT row (train_gan.py:152-155: 2 x 896 images, the target S-fold redundantly); here the
+    B x 8 = 1,024 unique frames go through the frozen encoder once (ndp_encoder_forward), then the fused step runs at
+    M = 5,376.  Both parts are timed on the launch stream; their sum is the image-mode step."""
+    from ndivplanning_amd.models.image_autoencoder import Encoder
+    from ndivplanning_amd.train_gan import encode_batch
+    batch, k = 128, 6
+    torch.manual_seed(0)
+    enc = Encoder().to(b.dev).eval()
+    gen = torch.Generator(device="cpu").manual_seed(4)
+    frames = (torch.rand(batch, TRAJ, 3, 128, 128, generator=gen) * 2.0 - 1.0).to(b.dev)
+    n_img = batch * TRAJ
+    flat_imgs = frames.reshape(n_img, 3, 128, 128)
+    with torch.no_grad():
+        codes128 = enc(flat_imgs)                                         # warm-up (packs parameters, allocates)
+        torch.cuda.synchronize(b.dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        nrep = 5
+        ev[0].record()
+        for _ in range(nrep):
+            codes128 = enc(flat_imgs)
+        ev[1].record()
+        torch.cuda.synchronize(b.dev)
+    enc_ms = ev[0].elapsed_time(ev[1]) / nrep
+    codes = encode_batch(codes128.reshape(batch, TRAJ, 128), None, TRAJ)  # [896, 256]
+    assert tuple(codes.shape) == (batch * (TRAJ - 1), 256) and bool(torch.isfinite(codes).all())
+    tr = b.make_trainer(batch, k, batch * (TRAJ - 1), 4, None, None)
+    gen_a = torch.Generator().manual_seed(5)
+    actions = torch.rand(batch * (TRAJ - 1), 4, generator=gen_a) * 2.0 - 1.0
+    for slot in range(tr.nslots):
+        tr.codes_slots[slot].copy_(codes)
+        tr.actions_slots[slot].copy_(actions)
+    sec, reps = b.timed(tr, steps, max(steps // 4, 8))
+    step_ms = 1e3 * sec / steps
+    losses = tr.losses()
+    enc_tflops = ENCODER_FLOP_PER_IMAGE * n_img / (enc_ms * 1e-3) / 1e12
+    m = batch * (TRAJ - 1) * k
+    out = {"workload": "BASELINE configs[3]: image-conditioned step, batch=128 trajectories x 8 frames of 3x128x128, "
+                       "num_sample=6; synthetic images, seeded random-init encoder",
+           "unique_images": n_img, "rows": m,
+           "encoder_ms": round(enc_ms, 4), "encoder_tflops": round(enc_tflops, 2),
+           "encoder_frac_of_fp32_mfma_peak": round(enc_tflops / MFMA_F32_PEAK_TFLOPS, 4),
+           "step_ms": round(step_ms, 5),
+           "step_frac_of_fp32_mfma_peak": round(step_flops(m) / (step_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+           "image_step_ms": round(enc_ms + step_ms, 4),
+           "image_steps_per_sec": round(1e3 / (enc_ms + step_ms), 2),
+           "cached_codes_steps_per_sec": round(1e3 / step_ms, 2),
+           "flops_as_reference_writes_it": "2 x 896 encoder passes = %.3f TFLOP/step; de-duplicated %.3f TFLOP/step"
+                                           % (ENCODER_FLOP_PER_IMAGE * 2 * 896 / 1e12, ENCODER_FLOP_PER_IMAGE * n_img / 1e12),
+           "last_losses": {"D": losses[0], "G": losses[1], "ndiv": losses[2]}}
+    del tr, enc, frames
+    torch.cuda.empty_cache()
+    return out
+
+
+def h2d_point(b, batch, k, steps, spl):
+    """Config 2 with a fresh batch per step uploaded from pinned host memory (what the reference's loop does per
+    iteration, train_gan.py:119-124), the upload of launch i+1 overlapped with the graph of launch i."""
+    tr = b.make_trainer(batch, k, batch * (TRAJ - 1), spl, None, None)
+    flat = batch * (TRAJ - 1)
+    gen = torch.Generator().manual_seed(77)
+    pool = 4                                                              # rotating host batches of spl steps each
+    host_c = [torch.randn(spl, flat, 256, generator=gen).pin_memory() for _ in range(pool)]
+    host_a = [(torch.rand(spl, flat, 4, generator=gen) * 2.0 - 1.0).pin_memory() for _ in range(pool)]
+    b.fill_slots(tr, batch, k)
+    state = {"i": 0}
+
+    def stepper():
+        i = state["i"] = (state["i"] + 1) % pool
+        tr.step_many_from_host(host_c[i], host_a[i])
+    n = max(steps - steps % spl, spl)
+    sec, reps = b.timed(tr, n, max(steps // 10, spl), stepper)
+    out = {"ms_per_step": round(1e3 * sec / n, 5), "steps_per_sec": round(n / sec, 2), "repeats": len(reps),
+           "bytes_per_step": flat * (256 + 4) * 4, "steps_per_upload": spl,
+           "how": "pinned host -> staging buffer on a copy stream during the previous graph launch, "
+                  "staging -> input slots on the launch stream (GanTrainer.step_many_from_host)"}
+    del tr
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    args = parse_args()
+    b = Bench(args)
+    world, rank, dev, dist, O = b.world, b.rank, b.dev, b.dist, b.O
+    batch, k = args.batch, args.num_sample
+    flat = batch * (TRAJ - 1)
+    m = flat * k
+    graph_ok = not args.no_graph
+    spl = args.steps_per_launch if (b.reduce_fn is None and graph_ok) else 1
+    tr = b.make_trainer(batch, k, flat * world, spl, b.p2p, b.reduce_fn, use_graph=graph_ok)
+
+    # step-0 parity figure (outside the timed region): NDiv / losses vs the oracle on rank 0's shard
+    parity = None
+    codes, actions, noise = O.synthetic_batch(1000 + rank, batch, k, NZ, steps=1)
+    if world == 1:
+        ref = O.StepMath({n_: v.clone() for n_, v in b.g0.items()}, {n_: v.clone() for n_, v in b.d0.items()})
+        out = ref.step(codes, actions, noise[0])
+        tr.step(codes.to(dev), actions.to(dev), noise[0].to(dev))
+        dl, gl, pd = tr.losses()
+        parity = {"ndiv_rel_err": abs(pd - out["pair_div"].item()) / max(1.0, abs(out["pair_div"].item())),
+                  "d_loss_abs_err": abs(dl - out["d_loss"].item()), "g_loss_abs_err": abs(gl - out["g_loss"].item()),
+                  "action_hat_max_abs_err": (tr.action_hat[:m].cpu() - out["action_hat"]).abs().max().item()}
+        del tr
+        tr = b.make_trainer(batch, k, flat * world, spl, b.p2p, b.reduce_fn, use_graph=graph_ok)
+    tr.codes.copy_(codes)
+    tr.actions.copy_(actions)
+    b.fill_slots(tr, batch, k)
+
+    if b.p2p is not None:
+        # a wait that timed out during warm-up (status word) means the exchange does not work on this
+        # node although its self-check passed: fall back to the RCCL path rather than time garbage
+        b.barrier()
+        b.run_steps(tr, max(args.warmup, spl))
+        bad = torch.tensor([b.p2p.status()], dtype=torch.int32, device=dev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()) != 0:
+            b.log("peer-to-peer exchange timed out in warm-up (%s); falling back to RCCL" % (b.p2p.diagnostics(),))
+            del tr
+            b.p2p.close()
+            b.p2p, b.reduce_fn, b.exchange, spl = None, b.dp.sum_all_reduce(), "rccl (p2p timed out in warm-up)", 1
+            tr = b.make_trainer(batch, k, flat * world, spl, None, b.reduce_fn, use_graph=graph_ok)
+            b.fill_slots(tr, batch, k)
+    elapsed, reps = b.timed(tr, args.steps, args.warmup)
+    losses = tr.losses()
+    hip_graph = bool(tr.use_graph)
+    kernels = kernel_table(b, tr, m)
 
     replicas_identical = None
     if world > 1:
@@ -260,10 +443,61 @@ def main():
         dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
         replicas_identical = bool(torch.equal(lo_, hi_))
-        if p2p is not None:
-            p2p.check()                # raises if any wait timed out
-            del tr
-            p2p.close()
+        if b.p2p is not None:
+            b.p2p.check()              # raises if any wait timed out
+    del tr
+    torch.cuda.empty_cache()
+
+    # ---- further workloads (every rank takes part in the N > 1 ones; failures never cost the headline line)
+    extras, extra_errors = {}, {}
+
+    def extra(name, fn):
+        try:
+            extras[name] = fn()
+        except Exception as exc:                                           # noqa: BLE001
+            extra_errors[name] = repr(exc)[:300]
+            b.log("extra %s failed: %r" % (name, exc))
+    if not args.no_extras:
+        if world > 1:
+            nsteps = min(args.steps, 400)
+
+            def dp_point(pb, pk, global_batch):
+                spl_ = args.steps_per_launch if (b.reduce_fn is None and graph_ok) else 1
+                t_ = b.make_trainer(pb, pk, global_batch * (TRAJ - 1), spl_, b.p2p, b.reduce_fn, use_graph=graph_ok)
+                b.fill_slots(t_, pb, pk, seed0=7000)
+                sec_, reps_ = b.timed(t_, nsteps, max(nsteps // 4, spl_))
+                if b.p2p is not None:
+                    b.p2p.check()
+                out_ = workload_summary(pb, pk, world, sec_, nsteps, reps_, {"gradient_exchange": b.exchange})
+                out_["global_steps_per_sec"] = out_["iterations_per_sec"]
+                del t_
+                torch.cuda.empty_cache()
+                return out_
+            if 256 % world == 0:
+                # BASELINE configs[2]: STRONG scaling -- the global batch of 256 split over the ranks (32 per GPU at N = 8)
+                extra("strong_config3", lambda: dict(dp_point(256 // world, 6, 256), scaling="strong",
+                                                     workload="BASELINE configs[2]: global batch 256 over %d ranks" % world))
+            # BASELINE configs[4]: K = 32, 128 trajectories per GPU (global 1,024 at N = 8)
+            extra("config5_shard", lambda: dict(dp_point(128, 32, 128 * world), scaling="weak",
+                                                workload="BASELINE configs[4] per-GPU shard: batch 128 x K=32 per rank"))
+            if b.p2p is not None:
+                # the same headline workload through the collective instead (8 eager kernels + 2 all-reduces per step)
+                def rccl_headline():
+                    t_ = b.make_trainer(batch, k, flat * world, 1, None, b.dp.sum_all_reduce(), use_graph=graph_ok)
+                    b.fill_slots(t_, batch, k)
+                    sec_, reps_ = b.timed(t_, nsteps, max(nsteps // 4, 8))
+                    out_ = workload_summary(batch, k, world, sec_, nsteps, reps_, {"gradient_exchange": "rccl"})
+                    out_["value_steps_per_sec"] = round(out_["iterations_per_sec"] * world, 2)
+                    del t_
+                    return out_
+                extra("headline_through_rccl", rccl_headline)
+        else:
+            extra("h2d_per_launch", lambda: h2d_point(b, batch, k, min(args.steps, 2000), spl if spl > 1 else 16))
+            extra("config4", lambda: config4_point(b, 200))
+            extra("large_m", lambda: {"config5_shard_b128_k32": large_m_point(b, 128, 32, 60),
+                                      "b1024_k6": large_m_point(b, 1024, 6, 60)})
+    if world > 1 and b.p2p is not None:
+        b.p2p.close()
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -273,7 +507,6 @@ def main():
     dom = max((n_ for n_ in kernels if KERNEL_MACS_PER_ROW.get(n_)), key=lambda n_: kernels[n_]["avg_us"] * kernels[n_]["launches_per_step"])
     dom_flops = 2.0 * KERNEL_MACS_PER_ROW[dom] * m
     achieved = dom_flops / (kernels[dom]["avg_us"] * 1e-6) / 1e12
-    step_flops = 2.0 * 629760 * m
     result = {
         "metric": "gan_train_steps_per_sec_traj8_batch64", "value": round(value, 2), "unit": "steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -284,22 +517,28 @@ def main():
                    "rows_per_gpu": m, "global_batch": batch * world, "parallelism": "dp%d" % world,
                    "trajectories_per_sec": round(iters_per_s * batch * world, 1),
                    "hip_graph": hip_graph, "steps_per_graph_launch": spl if hip_graph else 0,
-                   "gradient_exchange": exchange, "all_reduce_us": dict(dp.last_exchange_report) or None,
+                   "repeats": len(reps), "repeat_ms_per_step": [round(1e3 * r / args.steps, 5) for r in reps],
+                   "reported": "median repetition of %d x exactly %d steps, each bracketed by barrier + synchronize"
+                               % (len(reps), args.steps),
+                   "gradient_exchange": b.exchange, "all_reduce_us": dict(b.dp.last_exchange_report) or None,
                    "replicas_bit_identical": replicas_identical, "last_losses": {"D": losses[0], "G": losses[1], "ndiv": losses[2]}},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                      "traffic": PMC_HBM_BYTES_DEFAULT.get(dom) if (batch, k) == (64, 6) else None,
-                     "traffic_source": "profiles/r01_v7_pmc_hbm.csv (rocprofv3 --pmc, bytes per launch)",
+                     "traffic_source": PMC_SOURCE,
                      "algorithmic_flops_per_launch": dom_flops,
-                     "whole_step": {"flops": step_flops,
-                                    "tflops": round(step_flops * iters_per_s / 1e12, 3),
-                                    "frac": round(step_flops * iters_per_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)},
+                     "whole_step": {"flops": step_flops(m),
+                                    "tflops": round(step_flops(m) * iters_per_s / 1e12, 3),
+                                    "frac": round(step_flops(m) * iters_per_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)},
                      "kernels": kernels},
     }
     if parity is not None:
         result["parity_step0"] = {k_: float("%.3e" % v) for k_, v in parity.items()}
+    result.update(extras)
+    if extra_errors:
+        result["extras_failed"] = extra_errors
     if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(batch, k, nz, args.cpu_seconds)
+        result["cpu_baseline"] = cpu_baseline(batch, k, NZ, args.cpu_seconds)
         result["cpu_baseline"]["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
     print(json.dumps(result))
     if dist.is_initialized():

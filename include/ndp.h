@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NDP_VERSION 110          /* 0.1.1: ndp_p2p_*, ndp_step_config.p2p */
+#define NDP_VERSION 120          /* 0.2.0: ndp_p2p_diagnostics / _status_async, ndp_device_pci_bus_id */
 
 #define NDP_OK            0
 #define NDP_E_ARG         1      /* bad argument (shape, alignment, null) */
@@ -268,6 +268,17 @@ int ndp_p2p_open(const void *handle, void **mapped_out); /* a PEER process's han
 int ndp_p2p_close(void *mapped);
 /* status word of the own region: 0 = ok, 1 + r = a wait for rank r timed out (HOST int out) */
 int ndp_p2p_status(const ndp_p2p *p2p, int32_t *status_out);
+/* What the first waiter that gave up was waiting for (HOST int32[NDP_P2P_DIAG_WORDS] out; synchronises):
+ * {status code, workgroup, net, expected step, flag value it saw, peer rank, 100 MHz ticks waited, 0}. */
+#define NDP_P2P_DIAG_WORDS 8
+int ndp_p2p_diagnostics(const ndp_p2p *p2p, int32_t *words_out);
+/* Copy the status word to PINNED host memory behind everything already enqueued on `stream`, without
+ * synchronising: a training loop polls the value of the previous launch for free and aborts early. */
+int ndp_p2p_status_async(const ndp_p2p *p2p, int32_t *pinned_host_out, void *stream);
+/* PCI bus id ("0000:c1:00.0") of the CURRENT device into out[len >= 16]: ranks that report the same id
+ * share a GPU, and the in-kernel exchange needs every rank's reduce kernel co-resident -- which only a
+ * GPU per rank guarantees (ndivplanning_amd/dp.py refuses the exchange for such ranks unless forced). */
+int ndp_device_pci_bus_id(char *out, int len);
 /* The exchange alone: out[i] = sum over ranks of in[i] (n <= the capacity of `net`'s inbox:
  * ndp_d_param_count() for net 0, ndp_g_param_count(NDP_MAX_NOISE_DIM) for net 1).  step_word:
  * device int32, same value on every rank, larger than at the previous exchange on this net. */

@@ -12,7 +12,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libndp_hip.so")
 SOURCES = ["ndp_kernels.hip"]
-DEPS = ["ndp_kernels.hip", "ndp_device.h", "ndp_capi.inc", os.path.join("..", "..", "include", "ndp.h")]
+DEPS = ["ndp_kernels.hip", "ndp_device.h", "ndp_capi.inc", "ndp_encoder.inc", os.path.join("..", "..", "include", "ndp.h")]
 
 
 def _hipcc():

@@ -17,7 +17,7 @@ ACTION_DIM = 4
 MAX_NOISE_DIM = 16
 MAX_SAMPLES = 256
 ROW_PAD = 32
-EXPECTED_VERSION = 110          # NDP_VERSION of include/ndp.h this binding was written against
+EXPECTED_VERSION = 120          # NDP_VERSION of include/ndp.h this binding was written against
 
 _lib = None
 
@@ -28,6 +28,7 @@ class NdpError(RuntimeError):
 
 P2P_MAX_RANKS = 8
 P2P_HANDLE_BYTES = 64
+P2P_DIAG_WORDS = 8
 
 
 class P2P(Structure):
@@ -91,6 +92,9 @@ SIGNATURES = {
     "ndp_p2p_open": (c_int, [c_void_p, POINTER(c_void_p)]),
     "ndp_p2p_close": (c_int, [c_void_p]),
     "ndp_p2p_status": (c_int, [POINTER(P2P), POINTER(c_int32)]),
+    "ndp_p2p_diagnostics": (c_int, [POINTER(P2P), POINTER(c_int32)]),
+    "ndp_p2p_status_async": (c_int, [POINTER(P2P), c_void_p, c_void_p]),
+    "ndp_device_pci_bus_id": (c_int, [ctypes.c_char_p, c_int]),
     "ndp_p2p_all_reduce": (c_int, [POINTER(P2P), c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "ndp_encoder_param_floats": (c_int64, []),
     "ndp_encoder_workspace_floats": (c_int64, [c_int64]),
@@ -132,8 +136,19 @@ def check(rc, what):
         raise NdpError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))
 
 
-def stream_ptr():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+def stream_ptr(device=None):
+    """The current HIP stream of `device` (default: the current device).  Launches must run on the
+    device that owns their buffers: take this inside `on_device(...)`, or pass the device."""
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def on_device(t):
+    """Context manager that makes the device of tensor / torch.device `t` current for the launches
+    inside it.  The library launches on whatever device is current (kernel attributes, stream), so a
+    module that lives on cuda:1 while cuda:0 is current -- the reference's default `gpu_id: 1` with
+    `torch.load(...).to(gpu_id)` and no set_device -- must switch for the duration of the call."""
+    dev = t.device if isinstance(t, torch.Tensor) else torch.device(t)
+    return torch.cuda.device(dev)
 
 
 def ptr(t):

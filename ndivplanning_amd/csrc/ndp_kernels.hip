@@ -1365,7 +1365,19 @@ __device__ __forceinline__ float p2p_sum(const P2PArgs& x, float g, int64_t p, b
       const long long t0 = wall_clock64();
       while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - step) < 0) {
         if (wall_clock64() - t0 > x.timeout_ticks) {     // exit condition every wave reaches
-          __hip_atomic_store(status, (uint32_t)(1 + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          // the first waiter to give up leaves a record of what it was waiting for in the spare status words
+          // (ndp_p2p_diagnostics): {code, workgroup, net, expected step, flag value seen, peer, ticks waited}
+          const uint32_t seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          uint32_t expected = 0u;
+          if (__hip_atomic_compare_exchange_strong(status, &expected, (uint32_t)(1 + t), __ATOMIC_RELAXED,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+            __hip_atomic_store(status + 1, (uint32_t)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(status + 2, (uint32_t)x.net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(status + 3, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(status + 4, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(status + 5, (uint32_t)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(status + 6, (uint32_t)(wall_clock64() - t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
           break;
         }
         __builtin_amdgcn_s_sleep(2);

@@ -32,9 +32,12 @@ class _NDivLoss(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=x.device)
         grad = torch.empty_like(x)
         partials = _capi.empty(lib.ndp_ndiv_partials(n, k), x)
-        _capi.check(lib.ndp_ndiv_fwd_bwd(_capi.ptr(x), cx, _capi.ptr(z), cz, n, k, 1.0, _capi.ptr(loss),
-                                         _capi.ptr(grad), _capi.ptr(partials), _capi.stream_ptr()),
-                    "ndp_ndiv_fwd_bwd")
+        if z.device != x.device:
+            raise _capi.NdpError("recodes are on %s, codes on %s" % (x.device, z.device))
+        with _capi.on_device(x):
+            _capi.check(lib.ndp_ndiv_fwd_bwd(_capi.ptr(x), cx, _capi.ptr(z), cz, n, k, 1.0, _capi.ptr(loss),
+                                             _capi.ptr(grad), _capi.ptr(partials), _capi.stream_ptr()),
+                        "ndp_ndiv_fwd_bwd")
         ctx.save_for_backward(grad)
         return loss
 

@@ -130,6 +130,8 @@ class P2PExchange:
         import ctypes
         self._mapped = []
         self._region = ctypes.c_void_p()
+        self._status_host = None
+        self.shared_device, self.bus_ids = False, []
         # Every rank runs the SAME sequence of collectives whatever fails locally (a rank that raised before a
         # collective would leave the others waiting in it): local errors are carried through and raised together.
         err = None
@@ -140,13 +142,21 @@ class P2PExchange:
                 _capi.check(self.lib.ndp_p2p_export(self._region, handle), "ndp_p2p_export")
             except Exception as exc:                                   # noqa: BLE001
                 err = repr(exc)
+            bus = ctypes.create_string_buffer(64)
+            if self.lib.ndp_device_pci_bus_id(bus, 64) != 0:
+                bus.value = b"?"
             handles = [None] * self.world
-            dist.all_gather_object(handles, (self.rank, os.getpid(), handle.raw, err), group=group)
+            dist.all_gather_object(handles, (self.rank, os.getpid(), handle.raw, err, bus.value.decode()), group=group)
+            # ranks that report the same PCI bus id share a GPU (tests, mis-set LOCAL_RANK): the hand-shake then
+            # depends on the scheduler keeping every rank's kernels resident at once, see shared_device
+            ids = [h[4] for h in handles]
+            self.shared_device = len(set(ids)) < len(ids)
+            self.bus_ids = ids
             self.struct = _capi.P2P()
             self.struct.world, self.struct.rank, self.struct.timeout_ms = self.world, self.rank, int(timeout_ms)
             if err is None and all(h[3] is None for h in handles):
                 try:
-                    for r, (src, pid, raw, _e) in enumerate(handles):
+                    for r, (src, pid, raw, _e, _bus) in enumerate(handles):
                         if src != r:
                             raise RuntimeError("peer-to-peer exchange: handle list out of rank order")
                         if r == self.rank:
@@ -197,17 +207,52 @@ class P2PExchange:
             self._capi.check(self.lib.ndp_p2p_status(self.pointer(), ctypes.byref(out)), "ndp_p2p_status")
         return int(out.value)
 
+    def diagnostics(self):
+        """The record the first waiter that gave up left behind (include/ndp.h, ndp_p2p_diagnostics) or None."""
+        import ctypes
+        words = (ctypes.c_int32 * self._capi.P2P_DIAG_WORDS)()
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)
+            self._capi.check(self.lib.ndp_p2p_diagnostics(self.pointer(), words), "ndp_p2p_diagnostics")
+        if words[0] == 0:
+            return None
+        return {"peer": words[0] - 1, "workgroup": words[1], "net": "G" if words[2] else "D", "expected_step": words[3],
+                "flag_seen": words[4], "waited_ms": (words[6] & 0xffffffff) / 1e5}
+
+    def _raise_timeout(self):
+        d = self.diagnostics() or {}
+        raise RuntimeError(
+            "peer-to-peer gradient exchange: rank %d timed out waiting for rank %s (net %s, workgroup %s: expected "
+            "step %s, saw flag %s after %.0f ms)%s"
+            % (self.rank, d.get("peer", "?"), d.get("net", "?"), d.get("workgroup", "?"), d.get("expected_step", "?"),
+               d.get("flag_seen", "?"), d.get("waited_ms", float("nan")),
+               "; ranks share a GPU (%s): the hand-shake needs every rank's kernels resident at the same time"
+               % ", ".join(self.bus_ids) if self.shared_device else ""))
+
     def check(self):
-        st = self.status()
-        if st != 0:
-            raise RuntimeError("peer-to-peer gradient exchange: rank %d timed out waiting for rank %d"
-                               % (self.rank, st - 1))
+        if self.status() != 0:
+            self._raise_timeout()
+
+    def poll(self):
+        """Free early-abort check for a training loop, called once per (graph) launch: enqueue an asynchronous copy
+        of the status word behind the work launched so far, and raise if the copy enqueued by an EARLIER call --
+        long complete -- already shows a timed-out wait.  Never synchronises."""
+        import ctypes
+        if self._status_host is None:
+            self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        if int(self._status_host[0]) != 0:
+            self._raise_timeout()
+        with torch.cuda.device(self.device):
+            self._capi.check(self.lib.ndp_p2p_status_async(self.pointer(), ctypes.c_void_p(self._status_host.data_ptr()),
+                                                           self._capi.stream_ptr()), "ndp_p2p_status_async")
 
     def reset(self):
         """Zero flags and status (collective: no exchange may be in flight on any rank)."""
         self._barrier()
         with torch.cuda.device(self.device):
             self._capi.check(self.lib.ndp_p2p_region_reset(self._region), "ndp_p2p_region_reset")
+        if self._status_host is not None:
+            self._status_host.zero_()
         self._barrier()
 
     def all_reduce(self, x, step_word, net=0, out=None):
@@ -216,17 +261,26 @@ class P2PExchange:
         c = self._capi
         c.require_gpu_f32(x, "x")
         out = torch.empty_like(x) if out is None else out
-        c.check(self.lib.ndp_p2p_all_reduce(self.pointer(), int(net), c.ptr(x), c.ptr(out), x.numel(), c.ptr(step_word),
-                                            c.stream_ptr()), "ndp_p2p_all_reduce")
+        with torch.cuda.device(self.device):
+            c.check(self.lib.ndp_p2p_all_reduce(self.pointer(), int(net), c.ptr(x), c.ptr(out), x.numel(),
+                                                c.ptr(step_word), c.stream_ptr()), "ndp_p2p_all_reduce")
         return out
 
-    def self_check(self, trials=6):
+    def self_check(self, trials=6, check_timeout_ms=200):
         """Exchange integer-valued vectors (their sums are exact in any order) on both nets and
         compare with torch.distributed's all-reduce.  Collective; True on EVERY rank only if all
         ranks saw exact results and no timeout.  Leaves the region reset."""
         ok = True
+        # a node on which the exchange does not work must cost milliseconds, not timeout_ms x waits: the check runs
+        # with its own short bound (the ranks enter it together, behind a barrier)
+        saved_timeout, self.struct.timeout_ms = self.struct.timeout_ms, int(check_timeout_ms)
         try:
             with torch.cuda.device(self.device):
+                # load the library's code object on this device first (the first launch of a process pays for it)
+                warm = torch.empty(4, dtype=torch.float32, device=self.device)
+                self._capi.check(self.lib.ndp_uniform_noise(self._capi.ptr(warm), 4, 0, None, self._capi.stream_ptr()),
+                                 "warm-up")
+                self._barrier()
                 word = torch.zeros(4, dtype=torch.int32, device=self.device)
                 for net, n in ((0, 58305), (1, 83780)):
                     for trial in range(1, trials + 1):
@@ -247,6 +301,7 @@ class P2PExchange:
             import sys
             print("ndivplanning_amd: peer-to-peer self-check raised %r" % (exc,), file=sys.stderr)
             ok = False
+        self.struct.timeout_ms = saved_timeout
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
         if dist.get_backend(self.group) == "nccl":
             flag = flag.to(self.device)
@@ -303,6 +358,30 @@ class P2PExchange:
 last_exchange_report = {}       # filled by make_exchange: measured all-reduce times on this node
 
 
+def measure_collective(device, n=83780, iters=40, group=None):
+    """Average GPU time (us, maximum over ranks) of one torch.distributed SUM all-reduce of n floats."""
+    device = torch.device(device)
+    nccl = dist.get_backend(group) == "nccl"
+    with torch.cuda.device(device):
+        y = torch.ones(n, device=device) if nccl else torch.ones(n)
+        for _ in range(4):
+            dist.all_reduce(y, group=group)
+        torch.cuda.synchronize(device)
+        dist.barrier(group=group)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        t0 = __import__("time").perf_counter()
+        ev[0].record()
+        for _ in range(iters):
+            dist.all_reduce(y, group=group)
+        ev[1].record()
+        torch.cuda.synchronize(device)
+        wall = (__import__("time").perf_counter() - t0) * 1e6 / iters
+        us = ev[0].elapsed_time(ev[1]) * 1e3 / iters if nccl else wall
+        t = torch.tensor([us], dtype=torch.float64, device=device if nccl else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t[0])
+
+
 def make_exchange(device, world, log=None):
     """Pick the gradient exchange of a data-parallel run: the in-kernel peer-to-peer exchange when
     it passes its self-check on this node, torch.distributed's all-reduce (RCCL) otherwise.
@@ -317,7 +396,17 @@ def make_exchange(device, world, log=None):
         p2p = None
         try:
             p2p = P2PExchange(device)
-            good = p2p.self_check()
+            good = True
+            if p2p.shared_device and want != "p2p":
+                # Precondition of the in-kernel hand-shake: every rank's reduce kernel is resident while the others
+                # wait for its flags.  One GPU per rank guarantees that; ranks SHARING a GPU depend on how the
+                # hardware scheduler interleaves the processes' queues (round 1: 4 ranks on one GPU timed out in
+                # 1 run of 3) -- so the collective is used there unless NDP_DP_EXCHANGE=p2p asks for it (tests).
+                good = False
+                if log:
+                    log("ranks share a GPU (%s): using the collective exchange" % ", ".join(p2p.bus_ids))
+            # (forced onto a shared GPU -- the tests -- the ranks' kernels time-slice: keep the long bound there)
+            good = good and p2p.self_check(check_timeout_ms=p2p.struct.timeout_ms if p2p.shared_device else 200)
             if good:
                 t_p2p, t_coll = p2p.measure()
                 last_exchange_report.update(p2p_us=round(t_p2p, 2), collective_us=round(t_coll, 2), floats=83780)
@@ -337,8 +426,19 @@ def make_exchange(device, world, log=None):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if flag.item() == 1:
             return p2p, None, "p2p"
+        if p2p is not None:
+            try:
+                p2p.close()                                      # collective: every rank is on this branch
+            except Exception:                                    # noqa: BLE001
+                pass
         if want == "p2p":
             raise RuntimeError("NDP_DP_EXCHANGE=p2p but the peer-to-peer exchange failed its self-check")
         if log:
             log("peer-to-peer exchange failed its self-check; using the RCCL all-reduce")
+    if world > 1 and "collective_us" not in last_exchange_report and torch.device(device).type == "cuda":
+        try:
+            last_exchange_report.update(collective_us=round(measure_collective(device), 2), floats=83780)
+        except Exception as exc:                                 # noqa: BLE001 - a report, not a requirement
+            if log:
+                log("could not time the collective: %r" % (exc,))
     return None, sum_all_reduce(), "rccl"

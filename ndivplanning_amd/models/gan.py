@@ -91,8 +91,9 @@ class _GForward(torch.autograd.Function):
         acts = _capi.empty(lib.ndp_g_acts_floats(m), z) if need_grad else None
         out = torch.empty((m, ACTION_DIM), dtype=torch.float32, device=z.device)
         noise_view = z[:, CODE_DIM:]
-        _capi.check(lib.ndp_g_forward(_capi.ptr(flat), nz, _capi.ptr(z), ld, 1, _capi.ptr(noise_view), ld, m,
-                                      _capi.ptr(acts), _capi.ptr(out), _capi.stream_ptr()), "ndp_g_forward")
+        with _capi.on_device(z):
+            _capi.check(lib.ndp_g_forward(_capi.ptr(flat), nz, _capi.ptr(z), ld, 1, _capi.ptr(noise_view), ld, m,
+                                          _capi.ptr(acts), _capi.ptr(out), _capi.stream_ptr()), "ndp_g_forward")
         ctx.module, ctx.m = module, m
         if need_grad:
             ctx.save_for_backward(z, acts)
@@ -110,9 +111,10 @@ class _GForward(torch.autograd.Function):
         grad = torch.empty_like(flat)
         ws = _capi.empty(lib.ndp_g_bwd_ws_floats(m, nz), z)
         noise_view = z[:, CODE_DIM:]
-        _capi.check(lib.ndp_g_backward(_capi.ptr(flat), nz, _capi.ptr(z), ld, 1, _capi.ptr(noise_view), ld, m,
-                                       _capi.ptr(acts), _capi.ptr(d_action), _capi.ptr(grad), _capi.ptr(ws),
-                                       _capi.stream_ptr()), "ndp_g_backward")
+        with _capi.on_device(z):
+            _capi.check(lib.ndp_g_backward(_capi.ptr(flat), nz, _capi.ptr(z), ld, 1, _capi.ptr(noise_view), ld, m,
+                                           _capi.ptr(acts), _capi.ptr(d_action), _capi.ptr(grad), _capi.ptr(ws),
+                                           _capi.stream_ptr()), "ndp_g_backward")
         grads, off = [], 0
         for p in module._param_list():
             n = p.numel()
@@ -154,6 +156,8 @@ class Decoder(_FlatParamsMixin, nn.Module):
                                       "(the reference detaches the codes, train_gan.py:152-153)")
         if z.stride(1) != 1:
             z = z.contiguous()
+        if self.fc1.weight.device != z.device:
+            raise _capi.NdpError("Decoder parameters are on %s, input on %s" % (self.fc1.weight.device, z.device))
         return _GForward.apply(z, self, *self._param_list())
 
 
@@ -164,8 +168,9 @@ class _DForward(torch.autograd.Function):
         flat = module.flat_parameters()
         m = action.shape[0]
         logits = torch.empty((m, 1), dtype=torch.float32, device=action.device)
-        _capi.check(lib.ndp_d_forward(_capi.ptr(flat), _capi.ptr(action), 1, _capi.ptr(code), code.stride(0), 1, m,
-                                      _capi.ptr(logits), _capi.stream_ptr()), "ndp_d_forward")
+        with _capi.on_device(action):
+            _capi.check(lib.ndp_d_forward(_capi.ptr(flat), _capi.ptr(action), 1, _capi.ptr(code), code.stride(0), 1, m,
+                                          _capi.ptr(logits), _capi.stream_ptr()), "ndp_d_forward")
         ctx.module, ctx.m = module, m
         ctx.save_for_backward(action, code)
         return logits
@@ -185,9 +190,10 @@ class _DForward(torch.autograd.Function):
         grad = torch.empty_like(flat) if want_params else None
         d_action = torch.empty_like(action) if want_action else None
         ws = _capi.empty(lib.ndp_d_bwd_ws_floats(m), action) if want_params else None
-        _capi.check(lib.ndp_d_backward(_capi.ptr(flat), _capi.ptr(action), 1, _capi.ptr(code), code.stride(0), 1, m,
-                                       _capi.ptr(d_logits), _capi.ptr(grad), _capi.ptr(d_action), _capi.ptr(ws),
-                                       _capi.stream_ptr()), "ndp_d_backward")
+        with _capi.on_device(action):
+            _capi.check(lib.ndp_d_backward(_capi.ptr(flat), _capi.ptr(action), 1, _capi.ptr(code), code.stride(0), 1, m,
+                                           _capi.ptr(d_logits), _capi.ptr(grad), _capi.ptr(d_action), _capi.ptr(ws),
+                                           _capi.stream_ptr()), "ndp_d_backward")
         grads, off = [], 0
         for p in module._param_list():
             n = p.numel()
@@ -222,6 +228,9 @@ class Discriminator(_FlatParamsMixin, nn.Module):
         action = action.contiguous()
         if state_code.stride(1) != 1:
             state_code = state_code.contiguous()
+        if not (self.fc1.weight.device == action.device == state_code.device):
+            raise _capi.NdpError("Discriminator parameters are on %s, inputs on %s / %s"
+                                 % (self.fc1.weight.device, action.device, state_code.device))
         return _DForward.apply(action, state_code, self, *self._param_list())
 
 

@@ -41,7 +41,12 @@ class Encoder(nn.Module):
         # mpc_eval.py:139-140) with grad mode on and the loaded parameters still requiring grad: an eval-mode forward
         # is therefore NOT differentiable with respect to the encoder's parameters here; only an input that itself
         # requires grad (or training mode) selects the PyTorch operators.
-        if x.is_cuda and not self.training and not (torch.is_grad_enabled() and x.requires_grad):
+        if not self.training and not (torch.is_grad_enabled() and x.requires_grad):
+            if not x.is_cuda:
+                # the GAN path's case has no CPU or eager fallback, like Decoder / Discriminator
+                from .. import _capi
+                raise _capi.NdpError("images are on %s: the eval-mode Encoder computes only on a ROCm GPU "
+                                     "(no CPU fallback)" % x.device)
             return _encoder_forward_hip(self, x)
         return self._forward_torch(x)
 

@@ -26,22 +26,27 @@ launch are staged into separate input slots, the arithmetic is unchanged),
 In data-parallel runs each rank caches only the trajectories of its own shard positions, so the
 cache fills over several epochs there.
 """
+import importlib
 import logging
 import os
 from argparse import ArgumentParser
 
-import numpy as np
-import torch
-from torch.utils import data
+# HSA reads this when the runtime initialises (the first torch.cuda call below): dmabuf IPC is the only
+# mode this platform's driver supports, and the peer-to-peer gradient exchange / RCCL need it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-from . import dp
-from .models.gan import Decoder, Discriminator
-from .models.image_autoencoder import Encoder
-from .trainer import GanTrainer
-from .utils.argparse_util import override_dotmap
-from .utils.cli_arguments.common_arguments import add_common_arguments
-from .utils.file import make_paths_absolute
-from .utils.trajectory_loader import PushDataset, SyntheticPushDataset
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from torch.utils import data  # noqa: E402
+
+from . import dp  # noqa: E402
+from .models.gan import Decoder, Discriminator  # noqa: E402
+from .models.image_autoencoder import Encoder  # noqa: E402
+from .trainer import GanTrainer  # noqa: E402
+from .utils.argparse_util import override_dotmap  # noqa: E402
+from .utils.cli_arguments.common_arguments import add_common_arguments  # noqa: E402
+from .utils.file import make_paths_absolute  # noqa: E402
+from .utils.trajectory_loader import PushDataset, SyntheticPushDataset  # noqa: E402
 
 
 def denorm(tensor):
@@ -55,6 +60,29 @@ def norm(image):
 def _get(cfg, key, default):
     v = cfg.get(key, None) if hasattr(cfg, "get") else None
     return default if v is None or (isinstance(v, dict) and not v) else v
+
+
+def bind_reference_class_paths():
+    """Whole-module checkpoints (train_gan.py:254-266) must record the classes as `models.gan.Decoder` /
+    `models.gan.Discriminator` (and the encoder as `models.image_autoencoder.Encoder`): those are the paths the
+    reference's evaluation scripts unpickle (control_evaluation.py:175-176).  The root-level shims with those
+    names rename the classes when imported; do that here, so that every way into train() -- the CLI entry, the
+    package, a test -- writes the same pickles.  Returns the names that could not be bound."""
+    missing = []
+    for name, classes in (("models.gan", (Decoder, Discriminator)), ("models.image_autoencoder", (Encoder,))):
+        try:
+            mod = importlib.import_module(name)
+        except ImportError:
+            mod = None
+        for cls in classes:
+            if mod is not None and getattr(mod, cls.__name__, None) is cls:
+                cls.__module__ = name
+            else:
+                missing.append("%s.%s" % (name, cls.__name__))
+    if missing:
+        logging.warning("checkpoints will record ndivplanning_amd.* class paths: %s do(es) not resolve to this "
+                        "implementation (is the repository root, with its models/ shims, on sys.path?)", ", ".join(missing))
+    return missing
 
 
 def make_dataset(config):
@@ -131,6 +159,7 @@ def train(config):
 
     torch.manual_seed(random_seed)          # train_gan.py:65-66: Decoder, then Discriminator, then shuffling
     np.random.seed(random_seed)
+    bind_reference_class_paths()
 
     display = None
     if rank == 0 and _get(config, "log_port", None):
@@ -220,7 +249,10 @@ def train(config):
             acts = actions[:, :-1].reshape(-1, actions.size(-1))                # train_gan.py:137
             noise = None
             if noise_source == "cpu":                                           # train_gan.py:44
-                noise = torch.FloatTensor(flat_local, num_sample, noise_dim).uniform_().to(device)
+                # every rank has the same CPU generator state: draw the GLOBAL batch's noise, the single-process
+                # stream, and keep this rank's rows (identical draws per rank would duplicate noise W-fold)
+                noise = torch.FloatTensor(flat_local * world, num_sample, noise_dim).uniform_()
+                noise = noise[rank * flat_local:(rank + 1) * flat_local].to(device)
             pending.append((codes, acts, noise))
             if len(pending) == group:
                 flush()

@@ -21,6 +21,19 @@ from . import _capi, dp
 from .models.gan import ACTION_DIM, CODE_DIM, Decoder, Discriminator
 
 
+def _on_own_device(fn):
+    """Run a GanTrainer method with the trainer's device current: launches, kernel attributes and graph capture
+    all act on the current device, which need not be the one the networks live on (reference default
+    `gpu_id: 1`, no set_device)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kw):
+        with torch.cuda.device(self.device):
+            return fn(self, *args, **kw)
+    return wrapper
+
+
 class GanTrainer:
     def __init__(self, decoder: Decoder, discriminator: Discriminator, *, flat: int, num_sample: int,
                  lr: float = 2e-4, betas=(0.5, 0.999), eps: float = 1e-8, pairwise_div_factor: float = 0.1,
@@ -82,9 +95,11 @@ class GanTrainer:
             raise _capi.NdpError("bad step configuration (flat=%d, num_sample=%d)" % (self.flat, self.k))
         self.workspace = torch.empty(nws, **f32)
         self._graphs = None
+        self._stage = None
         self._device_noise_now = False
         self._d_calls = 0
-        self._bind()
+        with torch.cuda.device(self.device):
+            self._bind()
 
     # -- plumbing ---------------------------------------------------------------
     def _versions(self):
@@ -96,7 +111,7 @@ class GanTrainer:
 
     def _repack(self):
         """Rebuild the lane-ordered weight copies the step kernels read (include/ndp.h)."""
-        _capi.check(self.lib.ndp_step_pack_params(ctypes.byref(self.cfg), ctypes.byref(self.buf), _capi.stream_ptr()),
+        _capi.check(self.lib.ndp_step_pack_params(ctypes.byref(self.cfg), ctypes.byref(self.buf), _capi.stream_ptr(self.device)),
                     "ndp_step_pack_params")
         self._seen_versions = self._versions()
 
@@ -123,12 +138,12 @@ class GanTrainer:
         _capi.check(self.lib.ndp_step_d_grads(ctypes.byref(self.cfg), ctypes.byref(buf),
                                               _capi.ptr(self.codes_slots[slot]), _capi.ptr(self.actions_slots[slot]),
                                               _capi.ptr(self.noise_slots[slot]), 1 if first else 0,
-                                              _capi.stream_ptr()), "ndp_step_d_grads")
+                                              _capi.stream_ptr(self.device)), "ndp_step_d_grads")
 
     def _phase_b(self, slot=0):
         _capi.check(self.lib.ndp_step_g_grads(ctypes.byref(self.cfg), ctypes.byref(self.buf),
                                               _capi.ptr(self.codes_slots[slot]), _capi.ptr(self.actions_slots[slot]),
-                                              _capi.ptr(self.noise_slots[slot]), _capi.stream_ptr()),
+                                              _capi.ptr(self.noise_slots[slot]), _capi.stream_ptr(self.device)),
                     "ndp_step_g_grads")
 
     # the step as a list of segments; between segments the data-parallel driver
@@ -146,11 +161,11 @@ class GanTrainer:
 
         def d_update():
             _capi.check(self.lib.ndp_step_apply_adam(ctypes.byref(self.cfg), ctypes.byref(self.buf), 0,
-                                                     _capi.stream_ptr()), "ndp_step_apply_adam")
+                                                     _capi.stream_ptr(self.device)), "ndp_step_apply_adam")
 
         def g_update():
             _capi.check(self.lib.ndp_step_apply_adam(ctypes.byref(self.cfg), ctypes.byref(self.buf), 1,
-                                                     _capi.stream_ptr()), "ndp_step_apply_adam")
+                                                     _capi.stream_ptr(self.device)), "ndp_step_apply_adam")
 
         fused = self.reduce_fn is None
         for it in range(self.discrim_steps):
@@ -163,22 +178,26 @@ class GanTrainer:
         return segs
 
     # dp.run_step backend protocol (non-fused mode)
+    @_on_own_device
     def d_grads(self, first):
         self._d_calls = 0 if first else self._d_calls + 1
         self._phase_a(first, self._device_noise_now, self._d_calls == self.discrim_steps - 1)
         return self.d_grad
 
+    @_on_own_device
     def apply_d(self, grad):
         _capi.check(self.lib.ndp_step_apply_adam(ctypes.byref(self.cfg), ctypes.byref(self.buf), 0,
-                                                 _capi.stream_ptr()), "ndp_step_apply_adam")
+                                                 _capi.stream_ptr(self.device)), "ndp_step_apply_adam")
 
+    @_on_own_device
     def g_grads(self):
         self._phase_b()
         return self.g_grad
 
+    @_on_own_device
     def apply_g(self, grad):
         _capi.check(self.lib.ndp_step_apply_adam(ctypes.byref(self.cfg), ctypes.byref(self.buf), 1,
-                                                 _capi.stream_ptr()), "ndp_step_apply_adam")
+                                                 _capi.stream_ptr(self.device)), "ndp_step_apply_adam")
 
     def _run_eager(self, device_noise):
         if self.reduce_fn is not None:
@@ -187,13 +206,15 @@ class GanTrainer:
             return
         for fn, _ in self._segments(device_noise):
             fn()
+        if self.p2p is not None:
+            self.p2p.poll()
 
     def _build_graphs(self, device_noise, nsteps=1):
         """Capture maximal runs of segments that need no collective in between; `nsteps`
         consecutive iterations (input slots 0..nsteps-1) when there is no collective at all."""
         # load the code object / set kernel attributes outside of capture
         tmp = torch.empty(4, dtype=torch.float32, device=self.device)
-        _capi.check(self.lib.ndp_uniform_noise(_capi.ptr(tmp), 4, 0, None, _capi.stream_ptr()), "warm-up")
+        _capi.check(self.lib.ndp_uniform_noise(_capi.ptr(tmp), 4, 0, None, _capi.stream_ptr(self.device)), "warm-up")
         torch.cuda.synchronize(self.device)
         plan, run = [], []
         all_segments = [sg for slot in range(nsteps) for sg in self._segments(device_noise, slot)]
@@ -214,6 +235,7 @@ class GanTrainer:
         return graphs
 
     # -- public -----------------------------------------------------------------
+    @_on_own_device
     def step(self, codes=None, actions=None, noise=None):
         """One training iteration.  `codes` [flat,256], `actions` [flat,4]: this rank's
         shard (None = keep the buffers' current contents); `noise` [flat,K,nz] or None to
@@ -242,7 +264,10 @@ class GanTrainer:
             g.replay()
             if grad is not None:
                 self.reduce_fn(grad)
+        if self.p2p is not None:
+            self.p2p.poll()          # a timed-out wait of an EARLIER launch aborts here (no synchronisation)
 
+    @_on_own_device
     def step_many(self, codes=None, actions=None, noise=None):
         """`steps_per_launch` consecutive iterations in ONE graph replay.  codes [n,flat,256],
         actions [n,flat,4], noise [n,flat,K,nz] (n = steps_per_launch); None keeps what the slots
@@ -262,6 +287,40 @@ class GanTrainer:
             return
         for slot in range(n):
             for fn, grad in self._segments(device_noise, slot):
+                fn()
+                if grad is not None:
+                    self.reduce_fn(grad)
+
+    @_on_own_device
+    def step_many_from_host(self, codes_host, actions_host):
+        """`steps_per_launch` iterations on a FRESH batch per slot that still sits in pinned host memory
+        (codes [n,flat,256], actions [n,flat,4]): the reference uploads every batch (train_gan.py:119-124).
+        The upload runs on a copy stream into a staging buffer while the previous graph launch is still
+        computing; the launch stream then only waits for it and moves staging -> input slots on the device
+        (a few us) ahead of the replay.  Device noise."""
+        self._check_bindings()
+        n = self.nslots
+        if not (codes_host.is_pinned() and actions_host.is_pinned()):
+            raise ValueError("step_many_from_host needs pinned host tensors (torch.Tensor.pin_memory())")
+        if self._stage is None:
+            self._stage = (torch.empty_like(self.codes_slots), torch.empty_like(self.actions_slots),
+                           torch.cuda.Stream(self.device), torch.cuda.Event(), torch.cuda.Event())
+        st_codes, st_actions, copy_stream, uploaded, consumed = self._stage
+        main = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(consumed)             # the previous launch has emptied the staging buffer
+            st_codes.copy_(codes_host.reshape(n, self.flat, CODE_DIM), non_blocking=True)
+            st_actions.copy_(actions_host.reshape(n, self.flat, ACTION_DIM), non_blocking=True)
+            uploaded.record(copy_stream)
+        main.wait_event(uploaded)
+        self.codes_slots.copy_(st_codes, non_blocking=True)
+        self.actions_slots.copy_(st_actions, non_blocking=True)
+        consumed.record(main)
+        if self.use_graph and self.reduce_fn is None:
+            self._replay(True, n)
+            return
+        for slot in range(n):
+            for fn, grad in self._segments(True, slot):
                 fn()
                 if grad is not None:
                     self.reduce_fn(grad)
@@ -288,6 +347,7 @@ class GanTrainer:
         self.loss_sums.zero_()
         return v[0], v[1], v[2]
 
+    @_on_own_device
     def load_adam_state(self, g_state, d_state):
         """Teacher-forcing hook for parity tests: {'m': flat, 'v': flat, 't': int} per network."""
         for (m, v, step), st in (((self.g_m, self.g_v, self.g_step), g_state), ((self.d_m, self.d_v, self.d_step), d_state)):

@@ -3,28 +3,21 @@
 CLI-over-YAML merge (argparse_util.py:62-71)."""
 import argparse
 import glob
-import operator
 import os
-from functools import reduce
-
-
-def get_from_dict(dictionary, key_list):
-    return reduce(operator.getitem, key_list, dictionary)
-
-
-def set_in_dict(dictionary, key_list, value):
-    get_from_dict(dictionary, key_list[:-1])[key_list[-1]] = value
 
 
 def listdir_nohidden(path):
+    """Entries of `path` whose names do not start with a dot (glob skips dot-files)."""
     return glob.glob(os.path.join(path, "*"))
 
 
 def file_exists(prospective_file):
-    file_path = os.path.join(os.getcwd(), prospective_file)
-    if not os.path.exists(file_path):
-        raise argparse.ArgumentTypeError("File: '{0}' does not exist".format(file_path))
-    return file_path
+    """argparse `type=`: resolve against the working directory, reject a missing file
+    with the reference's message (argparse_util.py:26-31)."""
+    resolved = os.path.join(os.getcwd(), prospective_file)
+    if os.path.exists(resolved):
+        return resolved
+    raise argparse.ArgumentTypeError("File: '{0}' does not exist".format(resolved))
 
 
 def _checked_dir(prospective_dir, mode, word):

@@ -48,6 +48,12 @@ def test_folded_packed_parameters_give_the_same_codes():
             h = F.relu(h)
     assert o == packed.numel()
     assert (h - want).abs().max() <= 1e-5 * want.abs().max()
-    # and the module itself (PyTorch operators on the CPU) is the reference computation
+    # and the module's training-mode / autograd body (PyTorch operators) is the reference computation
     with torch.no_grad():
-        assert torch.equal(enc(x), want) or (enc(x) - want).abs().max() <= 1e-7
+        got = enc._forward_torch(x)
+        assert torch.equal(got, want) or (got - want).abs().max() <= 1e-7
+    # the eval-mode forward is the HIP path only: a CPU tensor is rejected, never computed eagerly
+    from ndivplanning_amd._capi import NdpError
+    import pytest
+    with pytest.raises(NdpError):
+        enc(x)

@@ -79,3 +79,57 @@ def test_parameter_change_is_picked_up():
         enc.conv6.bias.add_(1.0)
         b = enc(x)
     assert torch.allclose(b, a + 1.0, atol=1e-6)
+
+
+def test_config4_image_conditioned_step_at_batch_128():
+    """BASELINE configs[3] at its size: B = 128 trajectories x 8 frames = 1,024 unique 3x128x128 images through
+    `ndp_encoder_forward` (two passes of 512), codes assembled as train_gan.py:152-155 does (current frame || target
+    frame), then ONE fused train step at FLAT = 896, M = 5,376 against the oracle on the same codes.
+    Encoder: fp64-adjudicated against the oracle on a 128-image slice that touches every trajectory and every frame
+    position of both passes; finite + same scale on the other 896.  Reference: train_gan.py:127-203,
+    models/image_autoencoder.py:35-49."""
+    from oracle import gan_oracle as O
+    from ndivplanning_amd.models.gan import Decoder, Discriminator
+    from ndivplanning_amd.train_gan import encode_batch
+    from ndivplanning_amd.trainer import GanTrainer
+    batch, traj, k = 128, 8, 6
+    state = EO.init_encoder_state(21, bn_seed=22)
+    enc = _encoder(state)
+    x = EO.synthetic_images(23, batch * traj)
+    with torch.no_grad():
+        codes128 = enc(x.to(DEV)).reshape(batch * traj, 128)
+    assert codes128.shape == (1024, 128) and bool(torch.isfinite(codes128).all())
+    idx = torch.arange(batch) * traj + (torch.arange(batch) % traj)          # trajectory b, frame b % 8
+    ref32 = EO.encoder_forward(state, x[idx]).reshape(batch, 128).double()
+    ref64 = EO.encoder_forward(state, x[idx], dtype=torch.float64).reshape(batch, 128)
+    got = codes128[idx.to(DEV)].cpu().double()
+    scale = ref64.abs().max()
+    bound = torch.maximum(1e-5 * scale * torch.ones_like(ref64), 4.0 * (ref32 - ref64).abs())
+    assert bool(((got - ref64).abs() <= bound).all()), float(((got - ref64).abs() / scale).max())
+    rest = torch.ones(batch * traj, dtype=torch.bool)
+    rest[idx] = False
+    r = codes128[rest.to(DEV)]
+    assert 0.5 * got.abs().mean() <= r.abs().mean().item() <= 2.0 * got.abs().mean()   # same distribution of inputs
+
+    codes = encode_batch(codes128.reshape(batch, traj, 128), None, traj)
+    assert codes.shape == (batch * (traj - 1), 256)
+    # row f = b * 7 + t holds [code(frame t of b) || code(frame 7 of b)]
+    assert torch.equal(codes[5 * 7 + 3, :128], codes128[5 * 8 + 3]) and torch.equal(codes[5 * 7 + 3, 128:], codes128[5 * 8 + 7])
+    gen = torch.Generator().manual_seed(24)
+    actions = torch.rand(batch * (traj - 1), 4, generator=gen) * 2.0 - 1.0
+    noise = torch.rand(batch * (traj - 1), k, 2, generator=gen)
+    g, d = O.init_params(0, 2)
+    sm = O.StepMath({n: v.clone() for n, v in g.items()}, {n: v.clone() for n, v in d.items()})
+    ref = sm.step(codes.cpu(), actions, noise)
+    dec, dis = Decoder(2), Discriminator()
+    dec.load_state_dict(g)
+    dis.load_state_dict(d)
+    tr = GanTrainer(dec.to(DEV), dis.to(DEV), flat=codes.shape[0], num_sample=k)
+    assert tr.m == 5376
+    tr.step(codes, actions.to(DEV), noise.to(DEV))
+    d_loss, g_loss, pd = tr.losses()
+    assert abs(d_loss - ref["d_loss"].item()) <= 1e-4 and abs(g_loss - ref["g_loss"].item()) <= 1e-4
+    assert abs(pd - ref["pair_div"].item()) <= 1e-4 * max(1.0, abs(ref["pair_div"].item()))
+    assert (tr.action_hat[:tr.m].cpu() - ref["action_hat"]).abs().max().item() <= 1e-4
+    g0 = torch.cat([v.reshape(-1) for v in g.values()]).to(DEV)
+    assert 0 < (tr.g_flat - g0).abs().max().item() <= 2.5 * 2e-4            # one Adam step happened, inside its bound

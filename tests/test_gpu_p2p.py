@@ -46,7 +46,7 @@ def _rank_main(rank, world, port, out_dir):
     dp.init_process_group("cuda:0")
     res = {}
     p2p = dp.P2PExchange("cuda:0", timeout_ms=20000)
-    res["self_check"] = p2p.self_check(trials=4)
+    res["self_check"] = p2p.self_check(trials=4, check_timeout_ms=20000) and p2p.shared_device
     # the exchange alone, odd sizes, both nets, many consecutive exchanges (parity double-buffering)
     word = torch.zeros(4, dtype=torch.int32, device="cuda")
     exact = True
@@ -90,9 +90,11 @@ def _rank_main(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-# (3, not 4: every rank's kernels must be resident together for the in-kernel hand-shake, and four processes' worth of
-# 253-register phase-A waves plus three waiting reduce kernels do not always fit ONE GPU -- seen as a bounded-wait
-# time-out, 1 run in 3; on a node every rank has a GPU of its own)
+# (2 and 3 ranks.  The hand-shake needs every rank's reduce kernel resident at the same time; ranks that are
+# processes on ONE GPU depend on how the hardware scheduler interleaves their queues for that -- round 1 saw a
+# bounded-wait time-out in 1 run of 3 with FOUR ranks and kept no record of it.  That precondition is now explicit:
+# dp.make_exchange refuses the exchange for ranks that share a GPU unless it is forced, as it is here, and a
+# time-out leaves a diagnostic record (test_p2p_wait_is_bounded_when_a_peer_never_pushes).)
 @pytest.mark.parametrize("world", [2, 3])
 def test_p2p_exchange_ranks_as_processes_on_one_gpu(tmp_path, world):
     mp.spawn(_rank_main, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
@@ -128,7 +130,39 @@ def test_p2p_wait_is_bounded_when_a_peer_never_pushes(tmp_path):
     res = [torch.load(os.path.join(str(tmp_path), "t%d.pt" % r)) for r in range(2)]
     assert res[0]["status"] == 2          # rank 0 waited for rank 1 (1 + 1)
     assert res[0]["seconds"] < 5.0
-    assert res[1]["status"] == 0
+    assert res[1]["status"] == 0 and res[1]["diag"] is None
+    # the record the first waiter left: which peer, which net, which exchange number it expected and what it saw
+    d = res[0]["diag"]
+    assert d["peer"] == 1 and d["net"] == "D" and d["expected_step"] == 1 and d["flag_seen"] == 0
+    assert 250 <= d["waited_ms"] <= 2000
+    assert "timed out waiting for rank 1" in res[0]["poll"] and "share a GPU" in res[0]["poll"]
+
+
+def _guard_main(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", NDP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.pop("NDP_DP_EXCHANGE", None)
+    import torch.distributed as dist
+    from ndivplanning_amd import dp
+    torch.cuda.set_device(0)
+    dp.init_process_group("cuda:0")
+    logs = []
+    p2p, reduce_fn, name = dp.make_exchange("cuda:0", world, log=logs.append)
+    torch.save({"p2p": p2p is not None, "reduce": reduce_fn is not None, "name": name, "logs": logs},
+               os.path.join(out_dir, "g%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_make_exchange_refuses_the_in_kernel_exchange_for_ranks_that_share_a_gpu(tmp_path):
+    """The hand-shake's precondition -- every rank's reduce kernel resident at once -- is only guaranteed with a GPU
+    per rank: `make_exchange` compares the ranks' PCI bus ids and, unless NDP_DP_EXCHANGE=p2p forces it, selects the
+    collective on every rank alike."""
+    mp.spawn(_guard_main, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), "g%d.pt" % r)) for r in range(2)]
+    for r in res:
+        assert not r["p2p"] and r["reduce"] and r["name"] == "rccl"
+        assert any("share a GPU" in m for m in r["logs"])
 
 
 def _timeout_main(rank, world, port, out_dir):
@@ -147,7 +181,15 @@ def _timeout_main(rank, world, port, out_dir):
         p2p.all_reduce(torch.ones(1000, device="cuda"), word, net=0)     # rank 1 never answers
         p2p.all_reduce(torch.ones(1000, device="cuda"), word + 1, net=0)  # sticky status: no second wait
     torch.cuda.synchronize()
-    res = {"status": p2p.status(), "seconds": time.time() - t0}
+    res = {"status": p2p.status(), "seconds": time.time() - t0, "diag": p2p.diagnostics()}
+    if rank == 0:
+        try:
+            p2p.poll()                       # first call only enqueues the copy of the status word ...
+            torch.cuda.synchronize()
+            p2p.poll()                       # ... the next one sees it and raises, with the record
+            res["poll"] = "no error"
+        except RuntimeError as exc:
+            res["poll"] = str(exc)
     torch.save(res, os.path.join(out_dir, "t%d.pt" % rank))
     p2p.close()
     dist.destroy_process_group()

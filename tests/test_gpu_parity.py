@@ -483,6 +483,71 @@ def test_data_parallel_two_shards_equal_global_batch():
         _ndiv_close(lsum[2], lw[2], "pair_div shares")
 
 
+def test_config3_eight_rank_shards_equal_the_whole_batch_oracle_step():
+    """BASELINE configs[2] (batch=256 data-parallel over 8 GPUs) in its per-rank geometry, emulated serially on one
+    GPU: 8 trainers of 32 trajectories each (FLAT 224, M = 1,344 rows, 84 row tiles) with `flat_global` = 1,792
+    (inv_m_global = 1/10,752), their D and G gradients SUMMED between the phases -- what the exchange does --
+    against the oracle's single-process step on the whole B = 256 batch (reference loop train_gan.py:172-203;
+    scaling rule SURVEY.md section 8e: BCE mean over the global rows, NDiv sum unscaled).  Gradients adjudicated
+    by fp64; loss shares must add up to the whole-batch losses; all replicas take the same Adam step."""
+    from ndivplanning_amd.trainer import GanTrainer
+    batch, k, world = 256, 6, 8
+    codes, actions, noise = O.synthetic_batch(31, batch, k, steps=1)
+    noise = noise[0]
+    flat, per = codes.shape[0], codes.shape[0] // world
+    assert (flat, per, per * k) == (1792, 224, 1344)
+    g, d = O.init_params(0, 2)
+    teacher = O.AutogradTrainer(g, d)
+    ref = teacher.step(codes, actions, noise)
+    g_post, d_post = teacher.params()
+    f64 = _fp64_grads(g, d, codes, actions, noise, 2e-4, 0.1, d_post=d_post)
+    ranks = []
+    for r in range(world):
+        dec, dis = _load_modules(g, d, 2)
+        t = GanTrainer(dec, dis, flat=per, num_sample=k, flat_global=flat, use_graph=False, reduce_fn=lambda grad: None)
+        assert abs(t.cfg.inv_m_global - 1.0 / 10752.0) < 1e-12
+        sl = slice(r * per, (r + 1) * per)
+        t.codes.copy_(codes[sl])
+        t.actions.copy_(actions[sl])
+        t.noise.copy_(noise[sl])
+        ranks.append(t)
+    segs = [t._segments(False) for t in ranks]          # d_grads | d_update | g_grads | g_update
+    summed = []
+    for i in range(len(segs[0])):
+        for r in range(world):
+            segs[r][i][0]()
+        if segs[0][i][1] is not None:
+            total = torch.zeros_like(segs[0][i][1])
+            for r in range(world):                      # rank order 0..W-1, as the exchange adds
+                total += segs[r][i][1]
+            summed.append(total.clone())
+            for r in range(world):
+                segs[r][i][1].copy_(total)
+        if i == 1:
+            # every replica has applied the same D update; continue the G phase from the reference's post-update D
+            # so that the G-gradient comparison sees arithmetic only (Adam turns last-bit gradient differences
+            # into +-lr moves, tests/test_oracle_golden.py)
+            d_floor = max(4.0 * (_flat(ref["d_grads"]).double() - f64["d"]).abs().max().item(), 2e-6)
+            for t in ranks:
+                _params_close_floor(t.d_flat, _flat(d_post), _flat(ref["d_grads"]), d_floor, 2e-4, 1, "D params")
+                assert torch.equal(t.d_flat, ranks[0].d_flat)
+                with torch.no_grad():
+                    t.d_flat.copy_(_flat(d_post))
+                t._repack()
+    _grad_close_adjudicated(summed[0], _flat(ref["d_grads"]), f64["d"], "config 3: D gradient, sum of 8 shards")
+    _grad_close_adjudicated(summed[1], _flat(ref["g_grads"]), f64["g"], "config 3: G gradient, sum of 8 shards")
+    g_floor = max(4.0 * (_flat(ref["g_grads"]).double() - f64["g"]).abs().max().item(), 2e-6 * 30)
+    for t in ranks:
+        _params_close_floor(t.g_flat, _flat(g_post), _flat(ref["g_grads"]), g_floor, 2e-4, 1, "G params")
+        assert torch.equal(t.g_flat, ranks[0].g_flat)
+    shares = [sum(t.losses()[i] for t in ranks) for i in range(3)]
+    _close(shares[0], ref["d_loss"], 1e-4, "config 3: D_loss shares")
+    _close(shares[1], ref["g_loss"], 1e-4, "config 3: G_loss shares")
+    _ndiv_close(shares[2], ref["pair_div"].item(), "config 3: pair_div shares")
+    ah = torch.cat([t.action_hat[:per * k] for t in ranks])
+    _close(ah, ref["action_hat"], 1e-4, "config 3: action_hat of the 8 shards")
+
+
 def test_adam_kernel_matches_oracle():
     from ndivplanning_amd import _capi
     lib = _capi.load()
@@ -622,3 +687,35 @@ def test_generator_inference_as_the_evaluation_scripts_call_it(tmp_path):
     ref = O.g_forward(g, torch.cat([codes[:, None].expand(-1, k, -1), noise], dim=2).reshape(-1, 258))
     ref = ref[-1] if isinstance(ref, (tuple, list)) else ref
     _close(out.reshape(-1, 4), ref.reshape(-1, 4), 1e-4, "action_hat (inference)")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: modules on a device that is not current")
+def test_modules_on_a_device_that_is_not_current():
+    """The reference's default config has `gpu_id: 1` and its evaluation scripts call `torch.load(...).to(gpu_id)`
+    without set_device: the modules and the trainer must launch on the device that owns their tensors, whatever
+    device is current."""
+    from ndivplanning_amd.diversity import compute_pairwise_divergence
+    from ndivplanning_amd.models.gan import Decoder, Discriminator
+    from ndivplanning_amd.trainer import GanTrainer
+    dev = torch.device("cuda", 1)
+    assert torch.cuda.current_device() == 0
+    g, d = O.init_params(0, 2)
+    dec, dis = Decoder(2), Discriminator()
+    dec.load_state_dict(g)
+    dis.load_state_dict(d)
+    dec, dis = dec.to(dev), dis.to(dev)
+    codes, actions, noise = O.synthetic_batch(3, 4, 6, 2, steps=1)
+    z = torch.cat([codes.repeat_interleave(6, 0), noise[0].reshape(-1, 2)], 1)
+    a = dec(z.to(dev))
+    assert a.device == dev and (a.cpu() - O.g_forward(g, z)).abs().max() <= 1e-4
+    logit = dis(a.detach(), z[:, :256].contiguous().to(dev))
+    assert logit.device == dev and torch.isfinite(logit).all()
+    nd = compute_pairwise_divergence(a.view(-1, 6, 4), noise[0].to(dev))
+    assert nd.device == dev and torch.isfinite(nd)
+    tr = GanTrainer(dec, dis, flat=codes.shape[0], num_sample=6)
+    ref = O.StepMath({n: v.clone() for n, v in g.items()}, {n: v.clone() for n, v in d.items()})
+    out = ref.step(codes, actions, noise[0])
+    tr.step(codes.to(dev), actions.to(dev), noise[0].to(dev))
+    dl, gl, pd = tr.losses()
+    assert abs(dl - out["d_loss"].item()) <= 1e-4 and abs(gl - out["g_loss"].item()) <= 1e-4
+    assert torch.cuda.current_device() == 0

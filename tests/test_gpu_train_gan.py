@@ -77,7 +77,7 @@ def test_checkpoints_are_reference_style_whole_modules(tmp_path):
 
 
 def test_image_mode_runs_and_code_cache_is_exact(tmp_path):
-    """Image mode end to end (MIOpen encoder -> HIP step), and the frozen-encoder code cache:
+    """Image mode end to end (hand-written HIP encoder, ndp_encoder_forward -> HIP step), and the frozen-encoder code cache:
     epochs served from the cache must reproduce the run that re-encodes every batch."""
     from ndivplanning_amd.train_gan import train
     hists = []
@@ -142,3 +142,52 @@ def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, exchange):
     g0, _ = O.init_params(0, 2)
     moved = (res[0]["g"] - torch.cat([v.reshape(-1) for v in g0.values()])).abs()
     assert 0 < moved.max() <= 2 * 2.5 * 2e-4                                              # two Adam steps happened
+
+
+def test_cli_entry_in_a_fresh_interpreter_pickles_reference_class_paths(tmp_path):
+    """`python train_gan.py --config-file ...` (the reference's command line) in a new interpreter that never
+    imports the `models.gan` shim by hand: the checkpoints must still record `models.gan.Decoder` /
+    `models.gan.Discriminator` (what control_evaluation.py:175-176 unpickles), not the package-internal path."""
+    import subprocess
+    import yaml
+    cfg = _config(tmp_path, 8, "codes", 8, epochs=1, stage=1, noise_source="device").toDict()
+    os.makedirs(cfg["gan_save_path"], exist_ok=True)
+    with open(tmp_path / "cfg.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "train_gan.py"), "--config-file", str(tmp_path / "cfg.yaml"),
+                          "--gan-save-path", cfg["gan_save_path"]], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:]
+    for name in ("gan_decoder_0.pt", "gan_discriminator_0.pt"):
+        blob = open(os.path.join(cfg["gan_save_path"], name), "rb").read()
+        # torch.save writes a zip whose data.pkl holds the class path in clear
+        assert b"models.gan" in blob and b"ndivplanning_amd.models" not in blob, name
+    # and train() entered through the package binds the same paths without anybody importing the shim first
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from ndivplanning_amd import train_gan as t\n"
+            "assert t.Decoder.__module__ == 'ndivplanning_amd.models.gan'\n"
+            "assert t.bind_reference_class_paths() == []\n"
+            "assert t.Decoder.__module__ == t.Discriminator.__module__ == 'models.gan'\n"
+            "assert t.Encoder.__module__ == 'models.image_autoencoder'\n" % ROOT)
+    res = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:]
+
+
+def test_two_ranks_with_cpu_noise_reproduce_the_single_process_epoch(tmp_path):
+    """`noise_source: cpu` in a data-parallel run: every rank draws the GLOBAL noise tensor from the (identical)
+    CPU stream and keeps its rows, so two ranks on halves of each batch of 8 see exactly the noise -- and
+    therefore the losses -- of one process on the whole batch (SURVEY.md section 8e rule ii)."""
+    from ndivplanning_amd import train_gan
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cfg = _config(tmp_path, 16, "codes", 8, noise_source="cpu")
+    mp.spawn(_rank_main, args=(2, port, cfg.toDict(), str(tmp_path), "p2p"), nprocs=2, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(2)]
+    assert torch.equal(res[0]["g"], res[1]["g"]) and torch.equal(res[0]["d"], res[1]["d"])
+    single = train_gan.train(_config(tmp_path, 16, "codes", 8, noise_source="cpu"))
+    (d2, g2, n2), (d1, g1, n1) = res[0]["hist"][0], single[0]
+    assert abs(d2 - d1) <= 1e-4 and abs(g2 - g1) <= 1e-4
+    assert abs(n2 - n1) <= 5e-2 * abs(n1)       # two free-running steps at FLAT = 56 (see test_epoch_matches_oracle_replay)
