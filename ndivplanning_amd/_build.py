@@ -10,7 +10,8 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libndp_hip.so")
+# NDP_LIB_PATH: load another build of the library (diagnostic builds with -DNDP_STAMPS / -DNDP_EXP_*; scripts/probe)
+LIB_PATH = os.environ.get("NDP_LIB_PATH") or os.path.join(LIB_DIR, "libndp_hip.so")
 SOURCES = ["ndp_kernels.hip"]
 DEPS = ["ndp_kernels.hip", "ndp_device.h", "ndp_capi.inc", "ndp_encoder.inc", os.path.join("..", "..", "include", "ndp.h")]
 
@@ -29,21 +30,23 @@ def is_stale():
     return any(os.path.getmtime(os.path.join(CSRC, d)) > built for d in DEPS)
 
 
-def build(force=False, verbose=False):
-    """Compile the HIP sources into ndivplanning_amd/lib/libndp_hip.so."""
-    if not force and not is_stale():
+def build(force=False, verbose=False, extra_flags=(), out_path=None):
+    """Compile the HIP sources into ndivplanning_amd/lib/libndp_hip.so (or a diagnostic variant: extra_flags,
+    out_path)."""
+    target = out_path or LIB_PATH
+    if out_path is None and not force and not is_stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-value", "-Wno-pass-failed"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH + ".tmp"]
+           "-Wno-unused-value", "-Wno-pass-failed"] + list(extra_flags)
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", target + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + res.stdout)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+    os.replace(target + ".tmp", target)
+    return target
 
 
 if __name__ == "__main__":

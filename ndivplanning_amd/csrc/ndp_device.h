@@ -89,6 +89,39 @@ __device__ __forceinline__ int dgrad_pack_offset(int j, int k, int in, int out) 
   return (((wave * nit + t) * 64 + 16 * q + c) * 4 + s) * v_ + v;
 }
 
+// Kernel arguments arrive through scalar loads from the kernarg segment.  hipcc places those loads at the kernel's
+// entry and, short of scalar registers for a 0.5 KB argument struct, serialises them: load 16 dwords, wait, park
+// them in VGPR lanes, load the next 16, wait ... -- five to six DEPENDENT scalar-cache misses (~0.3-0.4 us each at
+// kernel start) before the first weight load is issued: 2.3 us of a 26 us kernel (stamps + ISA, round 2).
+// load_kernargs<T>() reads the struct through the kernarg pointer instead: first one dword of each of its 64-byte
+// lines (independent loads, ONE wait; up to 8 lines = 512 bytes), then the fields -- which now hit the scalar
+// cache.  The kernel's by-value parameter only sizes and fills the segment; the body reads the copy.
+template <class T>
+__device__ __forceinline__ T load_kernargs() {
+  typedef const __attribute__((address_space(4))) void* kptr_t;
+  kptr_t kp = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  constexpr int LAST = (((int)sizeof(T) - 4) / 64) * 64;          // offset of the last line that holds a field
+  constexpr int O1 = 64 < LAST ? 64 : LAST, O2 = 128 < LAST ? 128 : LAST, O3 = 192 < LAST ? 192 : LAST,
+                O4 = 256 < LAST ? 256 : LAST, O5 = 320 < LAST ? 320 : LAST, O6 = 384 < LAST ? 384 : LAST,
+                O7 = 448 < LAST ? 448 : LAST;
+  static_assert(sizeof(T) <= 576, "argument struct too large for the 8-line prefetch");
+  uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
+  asm volatile(
+      "s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, %9\n\ts_load_dword %2, %8, %10\n\t"
+      "s_load_dword %3, %8, %11\n\ts_load_dword %4, %8, %12\n\ts_load_dword %5, %8, %13\n\t"
+      "s_load_dword %6, %8, %14\n\ts_load_dword %7, %8, %15\n\ts_waitcnt lgkmcnt(0)"
+      : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7)
+      : "s"(kp), "i"(O1), "i"(O2), "i"(O3), "i"(O4), "i"(O5), "i"(O6), "i"(O7)
+      : "memory");
+  // the struct is read through a pointer the compiler cannot trace back to the kernarg segment, so that none of its
+  // loads can be placed ahead of the line prefetch
+  uint64_t v = (uint64_t)kp;
+  asm volatile("" : "+s"(v) : "s"(t0 | t1 | t2 | t3 | t4 | t5 | t6 | t7));
+  T out;
+  __builtin_memcpy(&out, (kptr_t)v, sizeof(T));
+  return out;
+}
+
 // Where workgroup b starts its sweep of a layer's reduction steps (FwdW::kstep).  Blocks b, b + 8, b + 16, ...
 // share an XCD and its L2 (round-robin dispatch; speed only): consecutive ones get consecutive offsets.
 // -DNDP_NO_ROTATION: every workgroup starts at step 0 (the ablation the figure in DESIGN.md comes from).
@@ -165,9 +198,13 @@ struct FwdW {
     return ldg4<WALIGN>(wbase + (size_t)(n * 16) * ldw + 16 * tr);
   }
 
-  __device__ __forceinline__ void preload(const float* __restrict__ Wm, int ldw_,
-                                          const float* __restrict__ bias,
-                                          const float* __restrict__ Wt, int tail_n) {
+  // The layer's operands, no loads yet.  The loads are issued either at once (preload) or a slice per k-step of the
+  // PREVIOUS layer's loop (preload_slice, called by layer_*_run for its `next` argument): a burst of 24+ wave-loads
+  // holds the wave at the load instructions for 0.8 us -- the memory pipe accepts them only as fast as the data
+  // returns (stamps, round 2) -- during which it issues no MFMA; spread between the MFMAs of a loop they cost nothing.
+  const float* bias_p; const float* wt_p; int tail_n_;
+  __device__ __forceinline__ void bind(const float* __restrict__ Wm, int ldw_, const float* __restrict__ bias,
+                                       const float* __restrict__ Wt, int tail_n) {
     static_assert(IN % 16 == 0 && OUT % 64 == 0, "layer_fwd shape");
     static_assert((NIT & (NIT - 1)) == 0, "k-step rotation needs a power-of-two step count");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -176,29 +213,50 @@ struct FwdW {
     ldw = ldw_;
     rot = workgroup_rotation();
     wbase = PACKED ? Wm + 4 * lane : Wm + (size_t)(col0 + c) * ldw_ + 4 * q;
+    bias_p = bias + col0 + c;
+    wt_p = Wt != nullptr ? Wt + (size_t)(col0 + c) * ldw_ + 4 * q : nullptr;
+    tail_n_ = tail_n;
+  }
+  static constexpr int kItems = PF * NT;
+  // slice i of nslices: bias and tail weights with slice 0, ring fragment j with slice j * nslices / kItems
+  __device__ __forceinline__ void preload_slice(int i, int nslices) {
+    const int q = (threadIdx.x & 63) >> 4;
+    if (i == 0) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int col = col0 + n * 16 + c;
-      bias_r[n] = bias[col];
-      wtail[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (Wt != nullptr) {
+      for (int n = 0; n < NT; ++n) {
+        bias_r[n] = bias_p[n * 16];
+        wtail[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (wt_p != nullptr) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (4 * q + j < tail_n) wtail[n][j] = Wt[(size_t)col * ldw_ + 4 * q + j];
+          for (int j = 0; j < 4; ++j)
+            if (4 * q + j < tail_n_) wtail[n][j] = wt_p[(size_t)(n * 16) * ldw + j];
+        }
       }
     }
 #pragma unroll
     for (int p = 0; p < PF; ++p)
 #pragma unroll
-      for (int n = 0; n < NT; ++n) ring[p][n] = frag(n, p);
+      for (int n = 0; n < NT; ++n)
+        if ((p * NT + n) * nslices / kItems == i) ring[p][n] = frag(n, p);
+  }
+  __device__ __forceinline__ void preload(const float* __restrict__ Wm, int ldw_,
+                                          const float* __restrict__ bias,
+                                          const float* __restrict__ Wt, int tail_n) {
+    bind(Wm, ldw_, bias, Wt, tail_n);
+    preload_slice(0, 1);
     pin_vmem();
   }
 };
 
-template <int RT, int IN, int OUT, int ACT, int WALIGN, bool PACKED, int RING>
+// `next` of a layer that has nothing to prefetch for
+struct NoPrefetch {
+  __device__ __forceinline__ void preload_slice(int, int) {}
+};
+
+template <int RT, int IN, int OUT, int ACT, int WALIGN, bool PACKED, int RING, class NEXT>
 __device__ __forceinline__ void layer_fwd_run(FwdW<IN, OUT, WALIGN, PACKED, RING>& w,
                                               const float* X, int ldx, float* Y, int ldy,
-                                              const float* Xt, int ldt) {
+                                              const float* Xt, int ldt, NEXT& next) {
   constexpr int NT = OUT / 64, NIT = IN / 16;
   constexpr int PF = FwdW<IN, OUT, WALIGN, PACKED, RING>::PF;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -233,6 +291,7 @@ __device__ __forceinline__ void layer_fwd_run(FwdW<IN, OUT, WALIGN, PACKED, RING
 #pragma unroll
       for (int n = 0; n < NT; ++n) w.ring[t % PF][n] = w.frag(n, t + PF);
     }
+    next.preload_slice(t, NIT);          // the following layer's first fragments, a slice per k-step
     if (t + 1 < NIT) {
       const int tr = w.kstep(t + 1);
 #pragma unroll
@@ -279,6 +338,13 @@ __device__ __forceinline__ void layer_fwd_run(FwdW<IN, OUT, WALIGN, PACKED, RING
         Y[row * ldy + col] = act_fwd<ACT>(acc[0][r][n][i] + w.bias_r[n]);
       }
   }
+}
+template <int RT, int IN, int OUT, int ACT, int WALIGN, bool PACKED, int RING>
+__device__ __forceinline__ void layer_fwd_run(FwdW<IN, OUT, WALIGN, PACKED, RING>& w,
+                                              const float* X, int ldx, float* Y, int ldy,
+                                              const float* Xt, int ldt) {
+  NoPrefetch none;
+  layer_fwd_run<RT, IN, OUT, ACT, WALIGN, PACKED, RING>(w, X, ldx, Y, ldy, Xt, ldt, none);
 }
 
 // ----------------------------------------------------------------------------------
@@ -329,7 +395,7 @@ struct DgW {
     }
   }
 
-  __device__ __forceinline__ void preload(const float* __restrict__ W, int ldw_) {
+  __device__ __forceinline__ void bind(const float* __restrict__ W, int ldw_) {
     static_assert((IN == 64 || IN == 128) && OUT % 16 == 0, "layer_dgrad shape");
     static_assert((NIT & (NIT - 1)) == 0, "reduction-step rotation needs a power-of-two step count");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -338,15 +404,23 @@ struct DgW {
     rot = workgroup_rotation();
     wbase = PACKED ? W + ((size_t)wave * NIT * 64 + lane) * (4 * V)
                    : W + (size_t)(4 * q) * ldw_ + wave * 16 * V + V * c;
+  }
+  // ring step p with slice p * nslices / PF (FwdW::preload_slice)
+  __device__ __forceinline__ void preload_slice(int i, int nslices) {
 #pragma unroll
-    for (int p = 0; p < PF; ++p) load_step(p, ring[p]);
+    for (int p = 0; p < PF; ++p)
+      if (p * nslices / PF == i) load_step(p, ring[p]);
+  }
+  __device__ __forceinline__ void preload(const float* __restrict__ W, int ldw_) {
+    bind(W, ldw_);
+    preload_slice(0, 1);
     pin_vmem();
   }
 };
 
-template <int RT, int IN, int OUT, int ACT, bool PACKED, int RING>
+template <int RT, int IN, int OUT, int ACT, bool PACKED, int RING, class NEXT>
 __device__ __forceinline__ void layer_dgrad_run(DgW<IN, OUT, PACKED, RING>& w, const float* dY, int ldd,
-                                                float* H, int ldh) {
+                                                float* H, int ldh, NEXT& next) {
   constexpr int V = IN / 64, NIT = OUT / 16;
   constexpr int PF = DgW<IN, OUT, PACKED, RING>::PF;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -377,6 +451,7 @@ __device__ __forceinline__ void layer_dgrad_run(DgW<IN, OUT, PACKED, RING>& w, c
 #pragma unroll
       for (int v = 0; v < V; ++v) bv[s][v] = w.ring[t % PF][s][v];
     if (t + PF < NIT) w.load_step(t + PF, w.ring[t % PF]);
+    next.preload_slice(t, NIT);
     if (t + 1 < NIT) {
       const int tr = w.kstep(t + 1);
 #pragma unroll
@@ -405,6 +480,12 @@ __device__ __forceinline__ void layer_dgrad_run(DgW<IN, OUT, PACKED, RING>& w, c
 #pragma unroll
       for (int v = 0; v < V; ++v) hp[v] = act_bwd<ACT>(hp[v], acc[0][r][v][i]);
     }
+}
+template <int RT, int IN, int OUT, int ACT, bool PACKED, int RING>
+__device__ __forceinline__ void layer_dgrad_run(DgW<IN, OUT, PACKED, RING>& w, const float* dY, int ldd,
+                                                float* H, int ldh) {
+  NoPrefetch none;
+  layer_dgrad_run<RT, IN, OUT, ACT, PACKED, RING>(w, dY, ldd, H, ldh, none);
 }
 
 // ----------------------------------------------------------------------------------

@@ -25,7 +25,7 @@ __device__ int g_stamp_kernel = 0;   // which kernel flushes: 1 k_g_fwd, 2 k_d, 
 #define NDP_STAMP_ON(id) (g_stamps != nullptr && (g_stamp_kernel == 0 || g_stamp_kernel == (id)))
 // stamps are kept in LDS (a global store per stamp would sit in the wave's vmcnt queue and
 // delay the next counted wait) and flushed by NDP_STAMP_FLUSH at the end of the kernel
-#define NDP_STAMP_DECL __shared__ unsigned long long stamp_store_[32]; unsigned long long* stamp_lds_ = stamp_store_
+#define NDP_STAMP_DECL __shared__ unsigned long long stamp_store_[64]; unsigned long long* stamp_lds_ = stamp_store_
 #define NDP_STAMP_PTR stamp_lds_
 #define NDP_STAMP(i)                                             \
   do {                                                           \
@@ -38,7 +38,7 @@ __device__ int g_stamp_kernel = 0;   // which kernel flushes: 1 k_g_fwd, 2 k_d, 
   do {                                                                                      \
     if (threadIdx.x == 0 && NDP_STAMP_ON(id))                                               \
       for (int i_ = 0; i_ < 2 * (n); ++i_)                                                  \
-        g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + i_] = stamp_lds_[i_]; \
+        g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + i_] = stamp_lds_[i_]; \
   } while (0)
 #else
 #define NDP_STAMP_DECL
@@ -178,19 +178,20 @@ __global__ __launch_bounds__(kThreads) void k_g_fwd(GFwdArgs a) {
   }
   __syncthreads();
   NDP_STAMP(1);
+  // every layer's first weight fragments are issued inside the previous layer's k-loop (FwdW::preload_slice)
   FwdW<128, 64, 4, PK> w2;
-  w2.preload(PK ? n.pf2 : n.w2, 128, n.b2, nullptr, 0);
-  layer_fwd_run<RT, 256, 128, ACT_RELU, W1ALIGN, PK>(w1, Xc, 260, H1, 132, Xt, TAILLD);
+  w2.bind(PK ? n.pf2 : n.w2, 128, n.b2, nullptr, 0);
+  layer_fwd_run<RT, 256, 128, ACT_RELU, W1ALIGN, PK>(w1, Xc, 260, H1, 132, Xt, TAILLD, w2);
   __syncthreads();
   NDP_STAMP(2);
   FwdW<64, 128, 4, PK> w3;
-  w3.preload(PK ? n.pf3 : n.w3, 64, n.b3, nullptr, 0);
-  layer_fwd_run<RT, 128, 64, ACT_RELU, 4, PK>(w2, H1, 132, H2, 68, nullptr, 0);
+  w3.bind(PK ? n.pf3 : n.w3, 64, n.b3, nullptr, 0);
+  layer_fwd_run<RT, 128, 64, ACT_RELU, 4, PK>(w2, H1, 132, H2, 68, nullptr, 0, w3);
   __syncthreads();
   NDP_STAMP(3);
   FwdW<128, 256, 4, PK> w4;
-  w4.preload(PK ? n.pf4 : n.w4, 128, n.b4, nullptr, 0);
-  layer_fwd_run<RT, 64, 128, ACT_RELU, 4, PK>(w3, H2, 68, H3, 132, nullptr, 0);
+  w4.bind(PK ? n.pf4 : n.w4, 128, n.b4, nullptr, 0);
+  layer_fwd_run<RT, 64, 128, ACT_RELU, 4, PK>(w3, H2, 68, H3, 132, nullptr, 0, w4);
   __syncthreads();
   NDP_STAMP(4);
   layer_fwd_run<RT, 128, 256, ACT_RELU, 4, PK>(w4, H3, 132, H4, 260, nullptr, 0);
@@ -406,13 +407,13 @@ __global__ __launch_bounds__(kThreads) void k_d(DArgs a) {
   __syncthreads();
   NDP_STAMP(1);
   FwdW<64, 128, 4, PK> w2;
-  w2.preload(PK ? n.pf2 : n.w2, 64, n.b2, nullptr, 0);
-  layer_fwd_run<RTT, 256, 64, ACT_LRELU, 4, PK>(w1, Xc, 260, H1, 68, Xt, TAILLD);
+  w2.bind(PK ? n.pf2 : n.w2, 64, n.b2, nullptr, 0);
+  layer_fwd_run<RTT, 256, 64, ACT_LRELU, 4, PK>(w1, Xc, 260, H1, 68, Xt, TAILLD, w2);
   __syncthreads();
   NDP_STAMP(2);
   FwdW<128, 256, 4, PK> w3;
-  w3.preload(PK ? n.pf3 : n.w3, 128, n.b3, nullptr, 0);
-  layer_fwd_run<RTT, 64, 128, ACT_LRELU, 4, PK>(w2, H1, 68, H2, 132, nullptr, 0);
+  w3.bind(PK ? n.pf3 : n.w3, 128, n.b3, nullptr, 0);
+  layer_fwd_run<RTT, 64, 128, ACT_LRELU, 4, PK>(w2, H1, 68, H2, 132, nullptr, 0, w3);
   __syncthreads();
   NDP_STAMP(3);
   layer_fwd_run<RTT, 128, 256, ACT_LRELU, 4, PK>(w3, H2, 132, H3, 260, nullptr, 0);
@@ -471,8 +472,8 @@ __global__ __launch_bounds__(kThreads) void k_d(DArgs a) {
   __syncthreads();
   NDP_STAMP(8);
   DgW<64, 128, PK> g2;
-  g2.preload(PK ? n.pg2 : n.w2, 64);
-  layer_dgrad_run<RTT, 128, 256, ACT_LRELU, PK>(g3, H3, 260, H2, 132);       // H2 := dY2
+  g2.bind(PK ? n.pg2 : n.w2, 64);
+  layer_dgrad_run<RTT, 128, 256, ACT_LRELU, PK>(g3, H3, 260, H2, 132, g2);   // H2 := dY2
   __syncthreads();
   NDP_STAMP(9);
   layer_dgrad_run<RTT, 64, 128, ACT_LRELU, PK>(g2, H2, 132, H1, 68);         // H1 := dY1
@@ -545,12 +546,12 @@ __global__ __launch_bounds__(kThreads) void k_g_bwd(GBwdArgs a) {
   layer_dgrad_narrow<RT, 256, 4, ACT_RELU>(DA, 4, n.w5, H4, 260);                // H4 := dY4
   __syncthreads();
   DgW<64, 128, PK> g3;
-  g3.preload(PK ? n.pg3 : n.w3, 64);
-  layer_dgrad_run<RT, 128, 256, ACT_RELU, PK>(g4, H4, 260, H3, 132);             // H3 := dY3
+  g3.bind(PK ? n.pg3 : n.w3, 64);
+  layer_dgrad_run<RT, 128, 256, ACT_RELU, PK>(g4, H4, 260, H3, 132, g3);         // H3 := dY3
   __syncthreads();
   DgW<128, 64, PK> g2;
-  g2.preload(PK ? n.pg2 : n.w2, 128);
-  layer_dgrad_run<RT, 64, 128, ACT_RELU, PK>(g3, H3, 132, H2, 68);               // H2 := dY2
+  g2.bind(PK ? n.pg2 : n.w2, 128);
+  layer_dgrad_run<RT, 64, 128, ACT_RELU, PK>(g3, H3, 132, H2, 68, g2);           // H2 := dY2
   __syncthreads();
   layer_dgrad_run<RT, 128, 64, ACT_RELU, PK>(g2, H2, 68, H1, 132);               // H1 := dY1
   __syncthreads();
@@ -608,8 +609,14 @@ struct PhaseAArgs {
   float* dy1seg; int seg_s, seg_entries;     // segment sums of dY1 (real + fake) [seg_entries x 64]
 };
 
-constexpr int phase_a_lds_floats(bool one_pass) {
-  return (one_pass ? 16 : 32) * (260 + TAILLD + 132 + 68 + 2) + 16 * 260 + 16 * 4 + 8;
+// Small weights every tile needs -- G.fc5 [4 x 256] + bias, D.fc4 [256] + bias -- are staged in LDS once per workgroup:
+// read straight from global inside the narrow (VALU) layers they were a serial chain of L2 round trips (stamps: fc5
+// 0.9 us, D fc4 + loss 1.2 us, 4.9 us for the 64-step dA loop at large M).  The split variants have LDS to spare and
+// get a region of their own; the stacked variant must stay under 80 KB (two workgroups per CU) and parks fc5 in the
+// upper half of B2 (free during G's forward) and fc4 in B3 once G.h4 is dead.
+constexpr int kSW5 = 1024 + 8, kSW4 = 256 + 8;
+constexpr int phase_a_lds_floats(bool one_pass, bool split = true) {
+  return (one_pass ? 16 : 32) * (260 + TAILLD + 132 + 68 + 2) + 16 * 260 + 16 * 4 + 8 + (split ? kSW5 + kSW4 : 0);
 }
 
 // One D pass handled by a workgroup: which global pass (0 = real, 1 = fake), which 16-row tile.
@@ -622,27 +629,31 @@ struct TilePass { int gp; int tile; int64_t row0; bool valid; };
 template <int NP, bool PK, int RG, bool SEG_COMBINED>
 __device__ __forceinline__ void phase_a_d_part(const PhaseAArgs& a, const TilePass (&pass)[NP], int ntiles,
                                                FwdW<256, 64, 4, PK, RG>& dw1, float* XC, float* XT, float* B1,
-                                               float* B2, float* L, float* DL, float* red,
+                                               float* B2, float* L, float* DL, float* red, const float* W4S,
                                                unsigned long long* stamp_lds_) {
   constexpr int R = 16;
   constexpr int DR = R * NP;
   const DNet& d = a.d;
   (void)stamp_lds_;
+  // each layer's first weight fragments are issued inside the previous layer's k-loop (FwdW::preload_slice)
   FwdW<64, 128, 4, PK, RG> dw2;
-  dw2.preload(PK ? d.pf2 : d.w2, 64, d.b2, nullptr, 0);
+  dw2.bind(PK ? d.pf2 : d.w2, 64, d.b2, nullptr, 0);
   NDP_STAMP(10);
-  layer_fwd_run<NP, 256, 64, ACT_LRELU, 4, PK>(dw1, XC, 260, B2, 68, XT, TAILLD);      // D.h1 -> B2
+  layer_fwd_run<NP, 256, 64, ACT_LRELU, 4, PK>(dw1, XC, 260, B2, 68, XT, TAILLD, dw2); // D.h1 -> B2
   NDP_STAMP(11);
   __syncthreads();
   NDP_STAMP(3);
   FwdW<128, 256, 4, PK, RG> dw3;
-  dw3.preload(PK ? d.pf3 : d.w3, 128, d.b3, nullptr, 0);
-  layer_fwd_run<NP, 64, 128, ACT_LRELU, 4, PK>(dw2, B2, 68, B1, 132, nullptr, 0);      // D.h2 -> B1
+  dw3.bind(PK ? d.pf3 : d.w3, 128, d.b3, nullptr, 0);
+  layer_fwd_run<NP, 64, 128, ACT_LRELU, 4, PK>(dw2, B2, 68, B1, 132, nullptr, 0, dw3); // D.h2 -> B1
   __syncthreads();
-  layer_fwd_run<NP, 128, 256, ACT_LRELU, 4, PK>(dw3, B1, 132, XC, 260, nullptr, 0);    // D.h3 -> XC (code tile is dead)
+  // (the backward's first layer too: its fragments wait in registers through the narrow fc4 / loss stages)
+  DgW<128, 256, PK, RG> dg3;
+  dg3.bind(PK ? d.pg3 : d.w3, 128);
+  layer_fwd_run<NP, 128, 256, ACT_LRELU, 4, PK>(dw3, B1, 132, XC, 260, nullptr, 0, dg3);   // D.h3 -> XC (code tile is dead)
   __syncthreads();
   NDP_STAMP(4);
-  layer_fwd_narrow<NP, 256, 1>(XC, 260, d.w4, d.b4, L, 1);
+  layer_fwd_narrow<NP, 256, 1>(XC, 260, W4S, W4S + 256, L, 1);
   __syncthreads();
   float lsum = 0.f;
   if (threadIdx.x < DR) {
@@ -664,8 +675,6 @@ __device__ __forceinline__ void phase_a_d_part(const PhaseAArgs& a, const TilePa
     if (threadIdx.x == 0) a.loss_partials[blockIdx.x] = tot;
   }
   NDP_STAMP(5);
-  DgW<128, 256, PK, RG> dg3;
-  dg3.preload(PK ? d.pg3 : d.w3, 128);
 #pragma unroll
   for (int ps = 0; ps < NP; ++ps) {
     if (!pass[ps].valid) continue;
@@ -682,11 +691,11 @@ __device__ __forceinline__ void phase_a_d_part(const PhaseAArgs& a, const TilePa
   }
   __syncthreads();
   NDP_STAMP(6);
-  layer_dgrad_narrow<NP, 256, 1, ACT_LRELU>(DL, 1, d.w4, XC, 260);                     // XC := dY3
+  layer_dgrad_narrow<NP, 256, 1, ACT_LRELU>(DL, 1, W4S, XC, 260);                      // XC := dY3
   __syncthreads();
   DgW<64, 128, PK, RG> dg2;
-  dg2.preload(PK ? d.pg2 : d.w2, 64);
-  layer_dgrad_run<NP, 128, 256, ACT_LRELU, PK>(dg3, XC, 260, B1, 132);                 // B1 := dY2
+  dg2.bind(PK ? d.pg2 : d.w2, 64);
+  layer_dgrad_run<NP, 128, 256, ACT_LRELU, PK>(dg3, XC, 260, B1, 132, dg2);            // B1 := dY2
   __syncthreads();
   NDP_STAMP(7);
   layer_dgrad_run<NP, 64, 128, ACT_LRELU, PK>(dg2, B1, 132, B2, 68);                   // B2 := dY1
@@ -722,7 +731,10 @@ __device__ __forceinline__ void phase_a_d_part(const PhaseAArgs& a, const TilePa
 // doubling up and slowing the role-0 workgroups.  With more tiles than CUs the stacked form (!SPLIT:
 // 16 real + 16 fake rows of the same tile in one workgroup) is the better use of a CU.
 template <bool PK, int RG, bool SPLIT, bool PAIR>
-__global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseAArgs a) {
+__global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseAArgs a_segment) {
+  // one workgroup per CU (RG = 96): nothing hides the argument loads, read them in one round trip (load_kernargs);
+  // with several workgroups per CU the registers that costs are worth more
+  const PhaseAArgs a = RG >= 96 ? load_kernargs<PhaseAArgs>() : a_segment;
   constexpr int R = 16;
   constexpr int DR = (SPLIT && !PAIR) ? R : 2 * R;   // D rows the LDS regions are sized for
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -735,6 +747,8 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseA
   float* L = A + 16 * 4;             // DR
   float* DL = L + DR;                // DR
   float* red = DL + DR;              // 8
+  float* W5S = SPLIT ? red + 8 : B2 + 16 * 68;       // G.fc5 weights [4][256] + bias (kSW5 floats)
+  float* W4S = SPLIT ? red + 8 + kSW5 : B3;          // D.fc4 weights [256] + bias    (kSW4 floats)
   const int ntiles = (int)(a.mpad / R);
   const int role = SPLIT ? (int)((int)blockIdx.x >= ntiles) : 0;          // SPLIT: 0 = G + D(fake), 1 = D(real)
   const GNet& g = a.g;
@@ -749,6 +763,9 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseA
     // ---------------- G forward (rows 0..15 of the regions)
     FwdW<256, 128, 2, PK, RG> gw1;
     gw1.preload(PK ? g.pf1 : g.w1, g.ld1, g.b1, g.w1 + CODE, g.nz);
+    const f32x4 w5r = *reinterpret_cast<const f32x4*>(g.w5 + 4 * threadIdx.x);
+    const float b5r = g.b5[threadIdx.x & 3], w4r = d.w4[threadIdx.x], b4r = d.b4[0];
+    NDP_STAMP(24);
     for (int idx = threadIdx.x; idx < R * 64; idx += kThreads) {
       const int i = idx >> 6, k = 4 * (idx & 63);
       const int64_t row = row0 + i;
@@ -757,6 +774,7 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseA
       *reinterpret_cast<f32x4*>(XC + i * 260 + k) = v;
       if (!SPLIT) *reinterpret_cast<f32x4*>(XC + (R + i) * 260 + k) = v;       // the fake pass' copy
     }
+    NDP_STAMP(25);
     for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {
       const int i = idx / TAILLD, t = idx % TAILLD;
       const int64_t row = row0 + i;
@@ -771,32 +789,48 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseA
       }
       XT[idx] = v;
     }
+    *reinterpret_cast<f32x4*>(W5S + 4 * threadIdx.x) = w5r;
+    if (threadIdx.x < 4) W5S[1024 + threadIdx.x] = b5r;
+    if (SPLIT) {
+      W4S[threadIdx.x] = w4r;
+      if (threadIdx.x == 0) W4S[256] = b4r;
+    }
+    NDP_STAMP(26);
     __syncthreads();
     NDP_STAMP(1);
+    // every layer's first weight fragments are issued inside the previous layer's k-loop (FwdW::preload_slice)
     FwdW<128, 64, 4, PK, RG> gw2;
-    gw2.preload(PK ? g.pf2 : g.w2, 128, g.b2, nullptr, 0);
-    layer_fwd_run<1, 256, 128, ACT_RELU, 2, PK>(gw1, XC, 260, B1, 132, XT, TAILLD);      // h1 -> B1
+    gw2.bind(PK ? g.pf2 : g.w2, 128, g.b2, nullptr, 0);
+    layer_fwd_run<1, 256, 128, ACT_RELU, 2, PK>(gw1, XC, 260, B1, 132, XT, TAILLD, gw2); // h1 -> B1
     __syncthreads();
     NDP_STAMP(12);
     FwdW<64, 128, 4, PK, RG> gw3;
-    gw3.preload(PK ? g.pf3 : g.w3, 64, g.b3, nullptr, 0);
+    gw3.bind(PK ? g.pf3 : g.w3, 64, g.b3, nullptr, 0);
     store_tile<1, 128>(a.gh1 + row0 * 128, 128, B1, 132);
-    layer_fwd_run<1, 128, 64, ACT_RELU, 4, PK>(gw2, B1, 132, B2, 68, nullptr, 0);        // h2 -> B2
+    layer_fwd_run<1, 128, 64, ACT_RELU, 4, PK>(gw2, B1, 132, B2, 68, nullptr, 0, gw3);   // h2 -> B2
     __syncthreads();
     NDP_STAMP(13);
     FwdW<128, 256, 4, PK, RG> gw4;
-    gw4.preload(PK ? g.pf4 : g.w4, 128, g.b4, nullptr, 0);
+    gw4.bind(PK ? g.pf4 : g.w4, 128, g.b4, nullptr, 0);
+    NDP_STAMP(16);
     store_tile<1, 64>(a.gh2 + row0 * 64, 64, B2, 68);
-    layer_fwd_run<1, 64, 128, ACT_RELU, 4, PK>(gw3, B2, 68, B1, 132, nullptr, 0);        // h3 -> B1 (h1 is stored)
+    NDP_STAMP(17);
+    layer_fwd_run<1, 64, 128, ACT_RELU, 4, PK>(gw3, B2, 68, B1, 132, nullptr, 0, gw4);   // h3 -> B1 (h1 is stored)
+    NDP_STAMP(18);
     __syncthreads();
     NDP_STAMP(14);
-    dw1.preload(PK ? d.pf1 : d.w1 + ADIM, 260, d.b1, d.w1, ADIM);                         // D fc1 weights fly early
+    dw1.bind(PK ? d.pf1 : d.w1 + ADIM, 260, d.b1, d.w1, ADIM);                            // D fc1 weights fly during G fc4
+    NDP_STAMP(19);
     store_tile<1, 128>(a.gh3 + row0 * 128, 128, B1, 132);
-    layer_fwd_run<1, 128, 256, ACT_RELU, 4, PK>(gw4, B1, 132, B3, 260, nullptr, 0);      // h4 -> B3
+    NDP_STAMP(20);
+    layer_fwd_run<1, 128, 256, ACT_RELU, 4, PK>(gw4, B1, 132, B3, 260, nullptr, 0, dw1); // h4 -> B3
+    NDP_STAMP(21);
     __syncthreads();
     NDP_STAMP(15);
     store_tile<1, 256>(a.gh4 + row0 * 256, 256, B3, 260);
-    layer_fwd_narrow<1, 256, 4>(B3, 260, g.w5, g.b5, A, 4);                               // action_hat -> A
+    NDP_STAMP(22);
+    layer_fwd_narrow<1, 256, 4>(B3, 260, W5S, W5S + 1024, A, 4);                          // action_hat -> A
+    NDP_STAMP(23);
     if (!SPLIT) {
       // real actions -> XT rows 0..15 (the noise there is dead), zero pad
       for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {
@@ -807,6 +841,10 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseA
     }
     __syncthreads();
     NDP_STAMP(2);
+    if (!SPLIT) {                                                                         // G.h4 (B3) is dead: fc4 moves in
+      W4S[threadIdx.x] = w4r;
+      if (threadIdx.x == 0) W4S[256] = b4r;
+    }
     constexpr int FK = SPLIT ? 0 : 1;                                                     // LDS pass slot of the fake rows
     for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {                      // fake actions -> XT
       const int i = idx / TAILLD, t = idx % TAILLD;
@@ -823,10 +861,10 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseA
     // ---------------- D on the fake rows (split) or on real + fake rows (stacked)
     if (SPLIT) {
       const TilePass pass[1] = {{1, tile, row0, true}};
-      phase_a_d_part<1, PK, RG, false>(a, pass, ntiles, dw1, XC, XT, B1, B2, L, DL, red, NDP_STAMP_PTR);
+      phase_a_d_part<1, PK, RG, false>(a, pass, ntiles, dw1, XC, XT, B1, B2, L, DL, red, W4S, NDP_STAMP_PTR);
     } else {
       const TilePass pass[2] = {{0, tile, row0, true}, {1, tile, row0, true}};
-      phase_a_d_part<2, PK, RG, true>(a, pass, ntiles, dw1, XC, XT, B1, B2, L, DL, red, NDP_STAMP_PTR);
+      phase_a_d_part<2, PK, RG, true>(a, pass, ntiles, dw1, XC, XT, B1, B2, L, DL, red, W4S, NDP_STAMP_PTR);
     }
   } else {
     // ---------------- SPLIT, role 1: the real pass of one tile, or of two stacked tiles (PAIR)
@@ -842,6 +880,8 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseA
       pass[ps].row0 = pass[ps].valid ? (int64_t)t * R : a.mpad;     // rows >= m: zero inputs, zero loss, no stores
     }
     dw1.preload(PK ? d.pf1 : d.w1 + ADIM, 260, d.b1, d.w1, ADIM);
+    W4S[threadIdx.x] = d.w4[threadIdx.x];
+    if (threadIdx.x == 0) W4S[256] = d.b4[0];
     for (int idx = threadIdx.x; idx < NP * R * 64; idx += kThreads) {
       const int i = idx >> 6, k = 4 * (idx & 63);
       const int64_t row = ((NP == 1 || i < R) ? pass[0].row0 : pass[NP - 1].row0) + (i % R);
@@ -855,10 +895,10 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseA
       XT[idx] = (row < a.m && t < ADIM) ? a.actions[(row / a.action_rep) * ADIM + t] : 0.f;
     }
     __syncthreads();
-    phase_a_d_part<NP, PK, RG, false>(a, pass, ntiles, dw1, XC, XT, B1, B2, L, DL, red, NDP_STAMP_PTR);
+    phase_a_d_part<NP, PK, RG, false>(a, pass, ntiles, dw1, XC, XT, B1, B2, L, DL, red, W4S, NDP_STAMP_PTR);
   }
   NDP_STAMP(8);
-  NDP_STAMP_FLUSH(16, 5);
+  NDP_STAMP_FLUSH(32, 5);
 }
 
 // Phase B (train_gan.py:187-202) for one 16-row tile: D' forward with the updated D, G loss,
@@ -880,7 +920,7 @@ struct PhaseBArgs {
 // pre: G's saved activations h2..h4 and the action columns of D.fc1 are fetched into LDS regions of their own at
 // the start of the kernel (+30 KB) instead of into the dead D regions in the middle of it
 constexpr int phase_b_lds_floats(bool pre) {
-  return 16 * (260 + TAILLD + 132 + 68 + 132 + 4 + 2) + 8 + (pre ? 256 + 16 * (260 + 132 + 68) : 0);
+  return 16 * (260 + TAILLD + 132 + 68 + 132 + 4 + 2) + 8 + 256 + kSW4 + kSW5 + (pre ? 16 * (260 + 132 + 68) : 0);
 }
 
 // PRE (one workgroup per CU, small M): the loads of G's activations for the backward half are issued with the
@@ -888,7 +928,8 @@ constexpr int phase_b_lds_floats(bool pre) {
 // stamps) overlaps the D' half; with several workgroups per CU (large M) other workgroups hide it and the LDS
 // is better spent on residency.
 template <bool PK, int RG, bool PRE>
-__global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseBArgs a) {
+__global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseBArgs a_segment) {
+  const PhaseBArgs a = RG >= 96 ? load_kernargs<PhaseBArgs>() : a_segment;   // see k_phase_a
   constexpr int R = 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XC = smem;                  // 16 x 260: code tile -> D.h3 / dY3 -> G.h4 / dY4
@@ -900,8 +941,10 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseB
   float* L = DA + R * 4;             // 16
   float* DL = L + R;                 // 16
   float* red = DL + R;               // 8
-  float* W1A = red + 8;              // PRE: 64 x 4 action columns of D.fc1
-  float* G4 = PRE ? W1A + 256 : XC;  // G.h4 / dY4   (!PRE: the D regions, loaded when they are dead)
+  float* W1A = red + 8;              // 64 x 4 action columns of D.fc1   } small weights staged once per workgroup
+  float* W4S = W1A + 256;            // D.fc4 [256] + bias                } (see phase_a_lds_floats)
+  float* W5S = W4S + kSW4;           // G.fc5 [4][256]                    }
+  float* G4 = PRE ? W5S + kSW5 : XC; // G.h4 / dY4   (!PRE: the D regions, loaded when they are dead)
   float* G3 = PRE ? G4 + R * 260 : B1;
   float* G2 = PRE ? G3 + R * 132 : B2;
   const int64_t row0 = (int64_t)blockIdx.x * R;
@@ -930,13 +973,19 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseB
   TileRegs<1, 256> t4;
   TileRegs<1, 128> t3;
   TileRegs<1, 64> t2;
-  float w1a = 0.f;
+  {
+    const float w1a = d.w1[(threadIdx.x >> 2) * 260 + (threadIdx.x & 3)], w4r = d.w4[threadIdx.x], b4r = d.b4[0];
+    const f32x4 w5r = *reinterpret_cast<const f32x4*>(g.w5 + 4 * threadIdx.x);
+    W1A[threadIdx.x] = w1a;
+    W4S[threadIdx.x] = w4r;
+    if (threadIdx.x == 0) W4S[256] = b4r;
+    *reinterpret_cast<f32x4*>(W5S + 4 * threadIdx.x) = w5r;
+  }
   if (PRE) {
     t1.load(a.gh1 + row0 * 128, 128);
     t4.load(a.gh4 + row0 * 256, 256);
     t3.load(a.gh3 + row0 * 128, 128);
     t2.load(a.gh2 + row0 * 64, 64);
-    w1a = d.w1[(threadIdx.x >> 2) * 260 + (threadIdx.x & 3)];
     pin_vmem();
   } else {
     load_tile<1, 128>(H1, 132, a.gh1 + row0 * 128, 128);                                 // needed last; region is free
@@ -944,24 +993,25 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseB
   __syncthreads();
   NDP_STAMP(1);
   FwdW<64, 128, 4, PK, RG> dw2;
-  dw2.preload(PK ? d.pf2 : d.w2, 64, d.b2, nullptr, 0);
-  layer_fwd_run<1, 256, 64, ACT_LRELU, 4, PK>(dw1, XC, 260, B2, 68, XT, TAILLD);        // D.h1 -> B2
+  dw2.bind(PK ? d.pf2 : d.w2, 64, d.b2, nullptr, 0);
+  layer_fwd_run<1, 256, 64, ACT_LRELU, 4, PK>(dw1, XC, 260, B2, 68, XT, TAILLD, dw2);   // D.h1 -> B2
   if (PRE) {                                                                             // regions of their own: no hazard
     t1.store(H1, 132);
     t4.store(G4, 260);
     t3.store(G3, 132);
     t2.store(G2, 68);
-    W1A[threadIdx.x] = w1a;
   }
   __syncthreads();
   FwdW<128, 256, 4, PK, RG> dw3;
-  dw3.preload(PK ? d.pf3 : d.w3, 128, d.b3, nullptr, 0);
-  layer_fwd_run<1, 64, 128, ACT_LRELU, 4, PK>(dw2, B2, 68, B1, 132, nullptr, 0);        // D.h2 -> B1
+  dw3.bind(PK ? d.pf3 : d.w3, 128, d.b3, nullptr, 0);
+  layer_fwd_run<1, 64, 128, ACT_LRELU, 4, PK>(dw2, B2, 68, B1, 132, nullptr, 0, dw3);   // D.h2 -> B1
   __syncthreads();
-  layer_fwd_run<1, 128, 256, ACT_LRELU, 4, PK>(dw3, B1, 132, XC, 260, nullptr, 0);      // D.h3 -> XC
+  DgW<128, 256, PK, RG> dg3;
+  dg3.bind(PK ? d.pg3 : d.w3, 128);
+  layer_fwd_run<1, 128, 256, ACT_LRELU, 4, PK>(dw3, B1, 132, XC, 260, nullptr, 0, dg3); // D.h3 -> XC
   __syncthreads();
   NDP_STAMP(2);
-  layer_fwd_narrow<1, 256, 1>(XC, 260, d.w4, d.b4, L, 1);
+  layer_fwd_narrow<1, 256, 1>(XC, 260, W4S, W4S + 256, L, 1);
   __syncthreads();
   float lsum = 0.f;
   if (threadIdx.x < R) {
@@ -980,15 +1030,15 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseB
   }
   __syncthreads();                      // DL
   NDP_STAMP(3);
-  DgW<128, 256, PK, RG> dg3;
-  dg3.preload(PK ? d.pg3 : d.w3, 128);
-  layer_dgrad_narrow<1, 256, 1, ACT_LRELU>(DL, 1, d.w4, XC, 260);                       // XC := D.dY3
+  layer_dgrad_narrow<1, 256, 1, ACT_LRELU>(DL, 1, W4S, XC, 260);                        // XC := D.dY3
   __syncthreads();
   DgW<64, 128, PK, RG> dg2;
-  dg2.preload(PK ? d.pg2 : d.w2, 64);
-  layer_dgrad_run<1, 128, 256, ACT_LRELU, PK>(dg3, XC, 260, B1, 132);                   // B1 := D.dY2
+  dg2.bind(PK ? d.pg2 : d.w2, 64);
+  layer_dgrad_run<1, 128, 256, ACT_LRELU, PK>(dg3, XC, 260, B1, 132, dg2);              // B1 := D.dY2
   __syncthreads();
-  layer_dgrad_run<1, 64, 128, ACT_LRELU, PK>(dg2, B1, 132, B2, 68);                     // B2 := D.dY1
+  DgW<128, 256, PK, RG> gg4;                                                             // G's backward starts streaming
+  gg4.bind(PK ? g.pg4 : g.w4, 128);
+  layer_dgrad_run<1, 64, 128, ACT_LRELU, PK>(dg2, B1, 132, B2, 68, gg4);                // B2 := D.dY1
   __syncthreads();
   NDP_STAMP(4);
   // dLoss/d action_hat = D.dY1 . W1[:, 0:4] (+ NDiv gradient) -> DA and dy5
@@ -997,7 +1047,7 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseB
     const int64_t row = row0 + i;
     float s = 0.f;
 #pragma unroll 8
-    for (int o = 0; o < 64; ++o) s = fmaf(B2[i * 68 + o], PRE ? W1A[o * 4 + j] : d.w1[o * 260 + j], s);
+    for (int o = 0; o < 64; ++o) s = fmaf(B2[i * 68 + o], W1A[o * 4 + j], s);
     if (row < a.m) {
       if (a.nd_grad != nullptr) s += a.nd_grad[row * ADIM + j];
     } else {
@@ -1010,8 +1060,6 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseB
   NDP_STAMP(5);
 
   // ---------------- G backward data path (!PRE: regions XC, B1, B2 are free again and take G's activations)
-  DgW<128, 256, PK, RG> gg4;
-  gg4.preload(PK ? g.pg4 : g.w4, 128);
   if (!PRE) {
     load_tile<1, 256>(G4, 260, a.gh4 + row0 * 256, 256);
     load_tile<1, 128>(G3, 132, a.gh3 + row0 * 128, 128);
@@ -1019,18 +1067,18 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseB
     __syncthreads();
   }
   NDP_STAMP(6);
-  layer_dgrad_narrow<1, 256, 4, ACT_RELU>(DA, 4, g.w5, G4, 260);                        // G4 := G.dY4
+  layer_dgrad_narrow<1, 256, 4, ACT_RELU>(DA, 4, W5S, G4, 260);                         // G4 := G.dY4
   __syncthreads();
   NDP_STAMP(7);
   DgW<64, 128, PK, RG> gg3;
-  gg3.preload(PK ? g.pg3 : g.w3, 64);
-  layer_dgrad_run<1, 128, 256, ACT_RELU, PK>(gg4, G4, 260, G3, 132);                    // G3 := G.dY3
+  gg3.bind(PK ? g.pg3 : g.w3, 64);
+  layer_dgrad_run<1, 128, 256, ACT_RELU, PK>(gg4, G4, 260, G3, 132, gg3);               // G3 := G.dY3
   __syncthreads();
   NDP_STAMP(8);
   DgW<128, 64, PK, RG> gg2;
-  gg2.preload(PK ? g.pg2 : g.w2, 128);
+  gg2.bind(PK ? g.pg2 : g.w2, 128);
   store_tile<1, 256>(a.dy4 + row0 * 256, 256, G4, 260);
-  layer_dgrad_run<1, 64, 128, ACT_RELU, PK>(gg3, G3, 132, G2, 68);                      // G2 := G.dY2
+  layer_dgrad_run<1, 64, 128, ACT_RELU, PK>(gg3, G3, 132, G2, 68, gg2);                 // G2 := G.dY2
   __syncthreads();
   NDP_STAMP(9);
   store_tile<1, 128>(a.dy3 + row0 * 128, 128, G3, 132);
@@ -1308,7 +1356,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
 #ifdef NDP_STAMPS
   NDP_WSTAMP(4);
   if (threadIdx.x == 0 && NDP_STAMP_ON(4))
-    for (int i_ = 0; i_ < 10; ++i_) g_stamps[(size_t)blockIdx.x * 32 + i_] = wst[i_];
+    for (int i_ = 0; i_ < 10; ++i_) g_stamps[(size_t)blockIdx.x * 64 + i_] = wst[i_];
 #endif
 }
 
@@ -1441,8 +1489,9 @@ __global__ __launch_bounds__(kThreads) void k_reduce_adam(ReduceArgs a) {
   if (live) {
     const float* sp = a.slabs + p;
     int nch = a.nchunks;
-    for (int r = 0; r < a.nregions; ++r)
-      if (p >= a.reg_begin[r] && p < a.reg_end[r]) nch = a.reg_slabs[r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r < a.nregions && p >= a.reg_begin[r] && p < a.reg_end[r]) nch = a.reg_slabs[r];
     // (the exchanging variant keeps 16 in flight: its waves hold their registers while they wait for the peers,
     // and with several ranks sharing one GPU in the tests a fat waiting kernel can keep a peer's kernels off the CUs)
     constexpr int NB = P2P ? 16 : 32;
@@ -1466,7 +1515,9 @@ __global__ __launch_bounds__(kThreads) void k_reduce_adam(ReduceArgs a) {
   // the loss scalars are the LAST block's job: the launch has one block more than the parameters need, so
   // this runs beside the parameter blocks instead of after one of them
   if (blockIdx.x == gridDim.x - 1) {
-    for (int t = 0; t < a.nloss; ++t) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      if (t >= a.nloss) break;
       const LossTerm lt = a.loss[t];
       float s = 0.f;
       for (int i = threadIdx.x; i < lt.count; i += kThreads) s += lt.partials[i];

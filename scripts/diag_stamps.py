@@ -30,7 +30,7 @@ tr.codes.copy_(codes); tr.actions.copy_(actions); tr.noise.copy_(noise[0])
 for _ in range(20):
     tr.step()
 torch.cuda.synchronize()
-stamps = torch.zeros(4096 * 32, dtype=torch.int64, device=dev)
+stamps = torch.zeros(4096 * 64, dtype=torch.int64, device=dev)
 KID = {"g": 1, "ga": 1, "d": 2, "da": 2, "db": 2, "w": 4, "wa": 4, "wb": 4, "pa": 5, "pb": 6}
 assert raw.ndp_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()), KID.get(os.environ.get("WHICH", "g"), 0)) == 0
 
@@ -39,7 +39,7 @@ def report(name, fn, nphase, nwg, first=0, skip=()):
         fn()
     stamps.zero_(); torch.cuda.synchronize()
     fn(); torch.cuda.synchronize()
-    s = stamps.cpu().numpy().reshape(-1, 16, 2)[first:first + nwg]
+    s = stamps.cpu().numpy().reshape(-1, 32, 2)[first:first + nwg]
     clk, wall = s[:, :, 0].astype(np.float64), s[:, :, 1].astype(np.float64)
     t0 = wall[:, 0].min()
     print("%s: %d workgroups; first start -> last end %.2f us; start skew %.2f us" % (
@@ -72,7 +72,7 @@ elif which == "wa":
     # per job: workgroup b -> xcd = b & 7, idx = b >> 3, job = idx % 19, chunk = xcd + 8 * (idx // 19)
     nchunks = int(os.environ.get("CH", 24))
     nblk = 8 * ((nchunks + 7) // 8) * 19
-    w = stamps.cpu().numpy().reshape(-1, 16, 2)[:nblk][:, :, 1].astype(np.float64)
+    w = stamps.cpu().numpy().reshape(-1, 32, 2)[:nblk][:, :, 1].astype(np.float64)
     t0 = w[w[:, 0] > 0, 0].min()
     names = ["fc1c0", "fc1c1", "fc1c2", "fc1c3", "fc1act", "fc2a", "fc2b"] + ["fc3_%d" % i for i in range(8)] + ["fc4_%d" % i for i in range(4)]
     for job in range(19):
@@ -90,19 +90,29 @@ elif which == "pa":
     report("k_phase_a role 0 [0 load,1 G fc1..fc4+fc5,2 a_hat->XT,3 D fc1,4 D fc2+fc3,5 D fc4+loss,6 stores,7 dg4+dg3,8 dg2+stores]",
            lambda: tr._phase_a(True), 8, mpad // 16)
     nt = mpad // 16
-    w0 = stamps.cpu().numpy().reshape(-1, 16, 2)[:nt][:, :, 1].astype(np.float64)
+    w0 = stamps.cpu().numpy().reshape(-1, 32, 2)[:nt][:, :, 1].astype(np.float64)
     print("role 0, inside phase 2->3: a_hat->XT + sync %.2f us | dw2.preload issue %.2f | fc1 k-loop+epilogue (wave 0) %.2f | barrier %.2f"
           % tuple(np.median(w0[:, b] - w0[:, a_]) / 100 for a_, b in ((2, 9), (9, 10), (10, 11), (11, 3))))
     print("role 0, G forward: fc1 %.2f us | fc2 %.2f | fc3 %.2f | fc4 %.2f | store h4 + fc5 + actions %.2f"
           % tuple(np.median(w0[:, b] - w0[:, a_]) / 100 for a_, b in ((1, 12), (12, 13), (13, 14), (14, 15), (15, 2))))
+    print("role 0, G fc3 stage: fc4 ring issue %.2f us | store h2 %.2f | k-loop + epilogue %.2f | barrier %.2f"
+          % tuple(np.median(w0[:, b] - w0[:, a_]) / 100 for a_, b in ((13, 16), (16, 17), (17, 18), (18, 14))))
+    print("role 0, G fc4 stage: D fc1 ring issue %.2f us | store h3 %.2f | k-loop + epilogue %.2f | barrier %.2f"
+          % tuple(np.median(w0[:, b] - w0[:, a_]) / 100 for a_, b in ((14, 19), (19, 20), (20, 21), (21, 15))))
+    print("role 0, prologue: fc1 ring issue %.2f us | code tile (load, LDS write) %.2f | noise %.2f | barrier %.2f"
+          % tuple(np.median(w0[:, b] - w0[:, a_]) / 100 for a_, b in ((0, 24), (24, 25), (25, 26), (26, 1))))
+    print("role 0, tail: store h4 %.2f us | fc5 (VALU) %.2f | barrier + rest %.2f"
+          % tuple(np.median(w0[:, b] - w0[:, a_]) / 100 for a_, b in ((15, 22), (22, 23), (23, 2))))
     if 128 < nt and nt + (nt + 1) // 2 <= 256:
-        s = stamps.cpu().numpy().reshape(-1, 16, 2)[nt:nt + (nt + 1) // 2]
+        s = stamps.cpu().numpy().reshape(-1, 32, 2)[nt:nt + (nt + 1) // 2]
         wall = s[:, :, 1].astype(np.float64)
-        all_ = stamps.cpu().numpy().reshape(-1, 16, 2)[:nt + (nt + 1) // 2][:, :, 1].astype(np.float64)
+        all_ = stamps.cpu().numpy().reshape(-1, 32, 2)[:nt + (nt + 1) // 2][:, :, 1].astype(np.float64)
         t0 = all_[:, 0].min()
         print("role 1 (paired real tiles): start median %.2f us after first start, end median %.2f (max %.2f); D fc1 done at %.2f, fwd done %.2f"
               % (np.median(wall[:, 0] - t0) / 100, np.median(wall[:, 8] - t0) / 100, (wall[:, 8] - t0).max() / 100,
                  np.median(wall[:, 3] - t0) / 100, np.median(wall[:, 4] - t0) / 100))
+        print("role 1 stages: prologue (ring issue, 2 code tiles, actions, barrier) %.2f us | D fc1 %.2f | barrier %.2f | fc2+fc3 %.2f | fc4+loss %.2f | stores %.2f | narrow+dg3 %.2f | dg2+seg+stores %.2f"
+              % tuple(np.median(wall[:, b] - wall[:, a_]) / 100 for a_, b in ((0, 10), (10, 11), (11, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8))))
         r0 = all_[:nt]
         print("role 0: end median %.2f us (max %.2f)" % (np.median(r0[:, 8] - t0) / 100, (r0[:, 8] - t0).max() / 100))
 elif which == "pb":
