@@ -122,17 +122,6 @@ __device__ __forceinline__ T load_kernargs() {
   return out;
 }
 
-// Where workgroup b starts its sweep of a layer's reduction steps (FwdW::kstep).  Blocks b, b + 8, b + 16, ...
-// share an XCD and its L2 (round-robin dispatch; speed only): consecutive ones get consecutive offsets.
-// -DNDP_NO_ROTATION: every workgroup starts at step 0 (the ablation the figure in DESIGN.md comes from).
-__device__ __forceinline__ int workgroup_rotation() {
-#ifdef NDP_NO_ROTATION
-  return 0;
-#else
-  return __builtin_amdgcn_readfirstlane((int)((blockIdx.x >> 3) * 5u + (blockIdx.x & 7u)));
-#endif
-}
-
 template <int WALIGN>
 __device__ __forceinline__ f32x4 ldg4(const float* p) {
 #ifdef NDP_EXP_NOLOAD     // diagnostic ablation: no weight traffic
@@ -180,22 +169,18 @@ struct FwdW {
   float bias_r[NT];
   const float* wbase;   // lane's base address (native: its weight row + 4q; packed: + 4*lane)
   int ldw;
-  int rot;              // k-step rotation of this workgroup, see kstep()
 
-  // Every workgroup of a launch streams the SAME weights; started together they also sweep them in the same
-  // order, and an L2 that is asked for the same lines by all ~21 CUs of an XCD at once, 24 fragments deep,
-  // delivers 20 B/clk/CU -- against 37-47 B/clk/CU when the CUs are at different places of the stream
-  // (scripts/probe/l2_stream.hip, measured).  So workgroup b starts its reduction at k-step rot = f(b) and
-  // wraps: a rotation of the summation order, which changes nothing but rounding.
-  __device__ __forceinline__ int kstep(int t) const { return (t + rot) & (NIT - 1); }
-
+  // (Tried, round 2: starting every workgroup's k sweep at a different step, because a microbenchmark of 168-256
+  // workgroups streaming the same packed weights in lockstep, 24 fragments deep, gets 20 B/clk/CU against 37-47
+  // when they are desynchronised -- scripts/probe/l2_stream.hip.  In the real kernels it changed nothing: with
+  // weight loads removed altogether (-DNDP_EXP_NOLOAD) they are no faster either.  The weight stream is not what
+  // these kernels wait for.)
   __device__ __forceinline__ f32x4 frag(int n, int t) const {
-    const int tr = kstep(t);
     if (PACKED) {
       const int wave = threadIdx.x >> 6;
-      return ldg4<4>(wbase + (size_t)((wave * NT + n) * NIT) * 256 + (size_t)tr * 256);
+      return ldg4<4>(wbase + (size_t)((wave * NT + n) * NIT + t) * 256);
     }
-    return ldg4<WALIGN>(wbase + (size_t)(n * 16) * ldw + 16 * tr);
+    return ldg4<WALIGN>(wbase + (size_t)(n * 16) * ldw + 16 * t);
   }
 
   // The layer's operands, no loads yet.  The loads are issued either at once (preload) or a slice per k-step of the
@@ -206,12 +191,10 @@ struct FwdW {
   __device__ __forceinline__ void bind(const float* __restrict__ Wm, int ldw_, const float* __restrict__ bias,
                                        const float* __restrict__ Wt, int tail_n) {
     static_assert(IN % 16 == 0 && OUT % 64 == 0, "layer_fwd shape");
-    static_assert((NIT & (NIT - 1)) == 0, "k-step rotation needs a power-of-two step count");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
     const int col0 = wave * (OUT / 4);
     ldw = ldw_;
-    rot = workgroup_rotation();
     wbase = PACKED ? Wm + 4 * lane : Wm + (size_t)(col0 + c) * ldw_ + 4 * q;
     bias_p = bias + col0 + c;
     wt_p = Wt != nullptr ? Wt + (size_t)(col0 + c) * ldw_ + 4 * q : nullptr;
@@ -277,11 +260,8 @@ __device__ __forceinline__ void layer_fwd_run(FwdW<IN, OUT, WALIGN, PACKED, RING
 
   // A operand: two register sets, step t+1 (or the tail) is read while step t computes
   f32x4 av[2][RT];
-  {
-    const int tr = w.kstep(0);
 #pragma unroll
-    for (int r = 0; r < RT; ++r) av[0][r] = *reinterpret_cast<const f32x4*>(xp + r * 16 * ldx + 16 * tr);
-  }
+  for (int r = 0; r < RT; ++r) av[0][r] = *reinterpret_cast<const f32x4*>(xp + r * 16 * ldx);
 #pragma unroll
   for (int t = 0; t < NIT; ++t) {
     f32x4 bv[NT];
@@ -293,9 +273,8 @@ __device__ __forceinline__ void layer_fwd_run(FwdW<IN, OUT, WALIGN, PACKED, RING
     }
     next.preload_slice(t, NIT);          // the following layer's first fragments, a slice per k-step
     if (t + 1 < NIT) {
-      const int tr = w.kstep(t + 1);
 #pragma unroll
-      for (int r = 0; r < RT; ++r) av[(t + 1) & 1][r] = *reinterpret_cast<const f32x4*>(xp + r * 16 * ldx + 16 * tr);
+      for (int r = 0; r < RT; ++r) av[(t + 1) & 1][r] = *reinterpret_cast<const f32x4*>(xp + r * 16 * ldx + 16 * (t + 1));
     } else if (Xt != nullptr) {
       // the "tail" (<= 16 extra inputs: noise / action) is one more 16-wide k-step with masked
       // weights; Xt rows are zero-padded to 16 in LDS
@@ -366,12 +345,8 @@ struct DgW {
   float ring[PF][4][V];
   const float* wbase;
   int ldw;
-  int rot;              // reduction-step rotation of this workgroup (FwdW::kstep)
 
-  __device__ __forceinline__ int kstep(int t) const { return (t + rot) & (NIT - 1); }
-
-  __device__ __forceinline__ void load_step(int t_, float (&dst)[4][V]) const {
-    const int t = kstep(t_);
+  __device__ __forceinline__ void load_step(int t, float (&dst)[4][V]) const {
     if (PACKED) {
       const float* p = wbase + (size_t)t * 64 * (4 * V);
 #pragma unroll
@@ -397,11 +372,9 @@ struct DgW {
 
   __device__ __forceinline__ void bind(const float* __restrict__ W, int ldw_) {
     static_assert((IN == 64 || IN == 128) && OUT % 16 == 0, "layer_dgrad shape");
-    static_assert((NIT & (NIT - 1)) == 0, "reduction-step rotation needs a power-of-two step count");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
     ldw = ldw_;
-    rot = workgroup_rotation();
     wbase = PACKED ? W + ((size_t)wave * NIT * 64 + lane) * (4 * V)
                    : W + (size_t)(4 * q) * ldw_ + wave * 16 * V + V * c;
   }
@@ -438,11 +411,8 @@ __device__ __forceinline__ void layer_dgrad_run(DgW<IN, OUT, PACKED, RING>& w, c
       for (int v = 0; v < V; ++v) acc[a][r][v] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   f32x4 av[2][RT];                                 // dY operand of step t+1 is read while step t computes
-  {
-    const int tr = w.kstep(0);
 #pragma unroll
-    for (int r = 0; r < RT; ++r) av[0][r] = *reinterpret_cast<const f32x4*>(dp + r * 16 * ldd + 16 * tr);
-  }
+  for (int r = 0; r < RT; ++r) av[0][r] = *reinterpret_cast<const f32x4*>(dp + r * 16 * ldd);
 #pragma unroll
   for (int t = 0; t < NIT; ++t) {
     float bv[4][V];
@@ -453,9 +423,8 @@ __device__ __forceinline__ void layer_dgrad_run(DgW<IN, OUT, PACKED, RING>& w, c
     if (t + PF < NIT) w.load_step(t + PF, w.ring[t % PF]);
     next.preload_slice(t, NIT);
     if (t + 1 < NIT) {
-      const int tr = w.kstep(t + 1);
 #pragma unroll
-      for (int r = 0; r < RT; ++r) av[(t + 1) & 1][r] = *reinterpret_cast<const f32x4*>(dp + r * 16 * ldd + 16 * tr);
+      for (int r = 0; r < RT; ++r) av[(t + 1) & 1][r] = *reinterpret_cast<const f32x4*>(dp + r * 16 * ldd + 16 * (t + 1));
     }
     pin_vmem_lds();
 #pragma unroll

@@ -10,6 +10,7 @@
 //   k_philox     uniform noise
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "ndp_device.h"
@@ -78,18 +79,19 @@ struct PackSpec {
 };
 
 __device__ __forceinline__ void pack_store(const PackSpec& ps, int p, float v) {
+  // (no early exits: the loop unrolls completely and every index into ps.L is static -- a by-value copy of the
+  // arguments then stays in registers)
 #pragma unroll
   for (int l = 0; l < 4; ++l) {
-    if (l >= ps.nl) break;
-    const PackLayer& L = ps.L[l];
+    const PackLayer L = ps.L[l];
     const int rel = p - L.w_off;
-    if (rel < 0 || rel >= L.out * L.ld) continue;
-    const int j = rel / L.ld, k = rel % L.ld;
-    const int km = k - L.main0;
-    if (L.fwd_off >= 0 && km >= 0 && km < L.main_in)
-      ps.packed[L.fwd_off + fwd_pack_offset(j, km, L.main_in, L.out)] = v;
-    if (L.dg_off >= 0) ps.packed[L.dg_off + dgrad_pack_offset(j, k, L.ld, L.out)] = v;
-    return;
+    if (l < ps.nl && rel >= 0 && rel < L.out * L.ld) {      // the layers' ranges are disjoint: at most one matches
+      const int j = rel / L.ld, k = rel % L.ld;
+      const int km = k - L.main0;
+      if (L.fwd_off >= 0 && km >= 0 && km < L.main_in)
+        ps.packed[L.fwd_off + fwd_pack_offset(j, km, L.main_in, L.out)] = v;
+      if (L.dg_off >= 0) ps.packed[L.dg_off + dgrad_pack_offset(j, k, L.ld, L.out)] = v;
+    }
   }
 }
 
@@ -1135,8 +1137,7 @@ struct WgradJob {
   int nchunks;         // row chunks (= slabs) of THIS job, <= WgradArgs::nchunks: the full 64 x 64 jobs take more
 };
 constexpr int kMaxJobs = 28;
-struct WgradArgs {
-  WgradJob job[kMaxJobs];
+struct WgradHead {     // what every workgroup reads: first in the argument struct, a few cache lines (see k_wgrad)
   int njobs;
   int rows;            // total rows (multiple of 16)
   float* slabs;        // [nchunks][slab_stride]
@@ -1145,6 +1146,9 @@ struct WgradArgs {
   float lr, beta1, beta2;
   int nchunks;         // maximum over the jobs: grid and slab count
   NdivArgs nd;         // blocks njobs*nchunks.. : NDiv (cx <= 4, cz <= 2) riding in this launch; nd.n == 0: none
+};
+struct WgradArgs : WgradHead {
+  WgradJob job[kMaxJobs];
   int net_is_g;        // host side only: kernel timing label
   int nreg, reg_begin[4], reg_end[4];   // host side only: layers whose jobs are "light" (fewer chunks)
 };
@@ -1316,8 +1320,35 @@ __device__ __forceinline__ void wgrad_block(const WgradJob& jb, int rbeg, int re
 
 constexpr int wgrad_lds_floats() { return kWaves * 64 * 64 + kWaves * 64; }
 
-__global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
+__global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a_segment) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // Arguments (load_kernargs explains why): the head's cache lines and the two lines of this workgroup's 88-byte job
+  // entry are requested together, one wait; head and entry are then copied out through a pointer the compiler
+  // cannot trace to the kernarg segment.  The 2.5 KB table itself is never read as a whole.
+  typedef const __attribute__((address_space(4))) char* kbytes_t;
+  static_assert(sizeof(WgradHead) <= 192 && offsetof(WgradArgs, job) % 8 == 0, "k_wgrad argument prefetch");
+  (void)a_segment;
+  WgradHead a;
+  WgradJob jb;
+  int job_id, chunk;
+  {
+    kbytes_t kp = (kbytes_t)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t h0, h1, h2;
+    asm volatile("s_load_dword %0, %3, 0x0\n\ts_load_dword %1, %3, 0x40\n\ts_load_dword %2, %3, 0x80\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(h0), "=&s"(h1), "=&s"(h2) : "s"(kp) : "memory");
+    const int njobs = (int)h0;                        // WgradHead::njobs is the first word
+    const int idx = blockIdx.x >> 3;
+    job_id = idx % njobs;
+    chunk = (int)(blockIdx.x & 7) + 8 * (idx / njobs);
+    const uint32_t joff = (uint32_t)(offsetof(WgradArgs, job) + (size_t)job_id * sizeof(WgradJob));
+    uint32_t j0, j1;
+    asm volatile("s_load_dword %0, %2, %3\n\ts_load_dword %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(j0), "=&s"(j1) : "s"(kp), "s"(joff), "s"(joff + (uint32_t)sizeof(WgradJob) - 4u) : "memory");
+    uint64_t v = (uint64_t)kp;
+    asm volatile("" : "+s"(v) : "s"(h0 | h1 | h2 | j0 | j1));
+    __builtin_memcpy(&a, (kbytes_t)v, sizeof(WgradHead));
+    __builtin_memcpy(&jb, (kbytes_t)v + joff, sizeof(WgradJob));
+  }
   // Linear grid with an XCD-aware order: workgroups are dealt round-robin over the 8 XCDs
   // (b % 8 labels the XCD; speed only, never correctness), and every job of a row chunk reads
   // the same activation rows, so all jobs of chunk c are given to XCD c % 8: the rows then cross
@@ -1330,9 +1361,6 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
     ndiv_block<4, 2>(a.nd, (int)blockIdx.x - slots, smem);
     return;
   }
-  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int job_id = idx % a.njobs, chunk = xcd + 8 * (idx / a.njobs);
-  const WgradJob& jb = a.job[job_id];
   if (chunk >= jb.nchunks) return;
   // a job's row space: all rows of the step (a.rows), or its own (segment-sum jobs)
   const int jrows = jb.rows != 0 ? jb.rows : a.rows;
@@ -1471,7 +1499,10 @@ __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& 
 }
 
 template <bool P2P>
-__global__ __launch_bounds__(kThreads) void k_reduce_adam(ReduceArgs a) {
+__global__ __launch_bounds__(kThreads) void k_reduce_adam(ReduceArgs a_segment) {
+  // single GPU: the arguments in one round trip (load_kernargs; the kernel is ~5 us, five serial scalar-cache
+  // misses were a third of it).  The exchanging variant indexes its peer table by rank and keeps the plain form.
+  const ReduceArgs a = P2P ? a_segment : load_kernargs<ReduceArgs>();
   __shared__ float sh[8];
   const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   const bool live = p < a.n;

@@ -96,6 +96,7 @@ class GanTrainer:
         self.workspace = torch.empty(nws, **f32)
         self._graphs = None
         self._stage = None
+        self._alt_slots = None
         self._device_noise_now = False
         self._d_calls = 0
         with torch.cuda.device(self.device):
@@ -131,33 +132,43 @@ class GanTrainer:
         self.buf_nosum.loss_sums = None
         self._repack()
 
-    def _phase_a(self, first, device_noise=False, last=True, slot=0):
+    def _inputs(self, slot, sset=0):
+        """(codes, actions, noise) buffers of input slot `slot`; sset 1 = the second slot set that
+        step_many_from_host alternates with (allocated on first use)."""
+        if sset == 0:
+            return self.codes_slots[slot], self.actions_slots[slot], self.noise_slots[slot]
+        if self._alt_slots is None:
+            self._alt_slots = (torch.zeros_like(self.codes_slots), torch.zeros_like(self.actions_slots),
+                               torch.zeros_like(self.noise_slots))
+        return tuple(t[slot] for t in self._alt_slots)
+
+    def _phase_a(self, first, device_noise=False, last=True, slot=0, sset=0):
         # device noise: the G forward kernel draws U[0,1) itself and fills the slot's noise buffer
         self.cfg.device_noise = 1 if device_noise else 0
         buf = self.buf if last else self.buf_nosum
-        _capi.check(self.lib.ndp_step_d_grads(ctypes.byref(self.cfg), ctypes.byref(buf),
-                                              _capi.ptr(self.codes_slots[slot]), _capi.ptr(self.actions_slots[slot]),
-                                              _capi.ptr(self.noise_slots[slot]), 1 if first else 0,
+        codes, actions, noise = self._inputs(slot, sset)
+        _capi.check(self.lib.ndp_step_d_grads(ctypes.byref(self.cfg), ctypes.byref(buf), _capi.ptr(codes),
+                                              _capi.ptr(actions), _capi.ptr(noise), 1 if first else 0,
                                               _capi.stream_ptr(self.device)), "ndp_step_d_grads")
 
-    def _phase_b(self, slot=0):
-        _capi.check(self.lib.ndp_step_g_grads(ctypes.byref(self.cfg), ctypes.byref(self.buf),
-                                              _capi.ptr(self.codes_slots[slot]), _capi.ptr(self.actions_slots[slot]),
-                                              _capi.ptr(self.noise_slots[slot]), _capi.stream_ptr(self.device)),
+    def _phase_b(self, slot=0, sset=0):
+        codes, actions, noise = self._inputs(slot, sset)
+        _capi.check(self.lib.ndp_step_g_grads(ctypes.byref(self.cfg), ctypes.byref(self.buf), _capi.ptr(codes),
+                                              _capi.ptr(actions), _capi.ptr(noise), _capi.stream_ptr(self.device)),
                     "ndp_step_g_grads")
 
     # the step as a list of segments; between segments the data-parallel driver
     # all-reduces the gradient the previous segment produced
-    def _segments(self, device_noise, slot=0):
+    def _segments(self, device_noise, slot=0, sset=0):
         segs = []
 
         def seg_d(first, last):
             def run():
-                self._phase_a(first, device_noise, last, slot)
+                self._phase_a(first, device_noise, last, slot, sset)
             return run
 
         def seg_g():
-            self._phase_b(slot)
+            self._phase_b(slot, sset)
 
         def d_update():
             _capi.check(self.lib.ndp_step_apply_adam(ctypes.byref(self.cfg), ctypes.byref(self.buf), 0,
@@ -209,7 +220,7 @@ class GanTrainer:
         if self.p2p is not None:
             self.p2p.poll()
 
-    def _build_graphs(self, device_noise, nsteps=1):
+    def _build_graphs(self, device_noise, nsteps=1, sset=0):
         """Capture maximal runs of segments that need no collective in between; `nsteps`
         consecutive iterations (input slots 0..nsteps-1) when there is no collective at all."""
         # load the code object / set kernel attributes outside of capture
@@ -217,7 +228,7 @@ class GanTrainer:
         _capi.check(self.lib.ndp_uniform_noise(_capi.ptr(tmp), 4, 0, None, _capi.stream_ptr(self.device)), "warm-up")
         torch.cuda.synchronize(self.device)
         plan, run = [], []
-        all_segments = [sg for slot in range(nsteps) for sg in self._segments(device_noise, slot)]
+        all_segments = [sg for slot in range(nsteps) for sg in self._segments(device_noise, slot, sset)]
         for fn, grad in all_segments:
             run.append(fn)
             if grad is not None:
@@ -253,13 +264,13 @@ class GanTrainer:
             return
         self._replay(device_noise, 1)
 
-    def _replay(self, device_noise, nsteps):
-        key = (bool(device_noise), nsteps)
+    def _replay(self, device_noise, nsteps, sset=0):
+        key = (bool(device_noise), nsteps, sset)
         if self._graphs is None:
             self._graphs = {}
         if key not in self._graphs:
             # capture performs no work; the first replay below is the step itself
-            self._graphs[key] = self._build_graphs(device_noise, nsteps)
+            self._graphs[key] = self._build_graphs(device_noise, nsteps, sset)
         for g, grad in self._graphs[key]:
             g.replay()
             if grad is not None:
@@ -295,35 +306,40 @@ class GanTrainer:
     def step_many_from_host(self, codes_host, actions_host):
         """`steps_per_launch` iterations on a FRESH batch per slot that still sits in pinned host memory
         (codes [n,flat,256], actions [n,flat,4]): the reference uploads every batch (train_gan.py:119-124).
-        The upload runs on a copy stream into a staging buffer while the previous graph launch is still
-        computing; the launch stream then only waits for it and moves staging -> input slots on the device
-        (a few us) ahead of the replay.  Device noise."""
+        Two sets of input slots alternate, each with its own captured graph: while the graph of one set computes,
+        the copy stream uploads the next launch's batches straight into the other set, and the launch stream only
+        waits for that upload's event before the replay -- nothing but the wait sits between two replays.
+        Device noise."""
         self._check_bindings()
         n = self.nslots
         if not (codes_host.is_pinned() and actions_host.is_pinned()):
             raise ValueError("step_many_from_host needs pinned host tensors (torch.Tensor.pin_memory())")
         if self._stage is None:
-            self._stage = (torch.empty_like(self.codes_slots), torch.empty_like(self.actions_slots),
-                           torch.cuda.Stream(self.device), torch.cuda.Event(), torch.cuda.Event())
-        st_codes, st_actions, copy_stream, uploaded, consumed = self._stage
+            self._stage = {"stream": torch.cuda.Stream(self.device), "next": 0,
+                           "uploaded": [torch.cuda.Event(), torch.cuda.Event()],
+                           "read": [torch.cuda.Event(), torch.cuda.Event()]}
+        st = self._stage
+        sset = st["next"]
+        st["next"] = 1 - sset
+        self._inputs(0, sset)                             # allocates the second set on first use
+        codes = self.codes_slots if sset == 0 else self._alt_slots[0]
+        actions = self.actions_slots if sset == 0 else self._alt_slots[1]
         main = torch.cuda.current_stream(self.device)
-        with torch.cuda.stream(copy_stream):
-            copy_stream.wait_event(consumed)             # the previous launch has emptied the staging buffer
-            st_codes.copy_(codes_host.reshape(n, self.flat, CODE_DIM), non_blocking=True)
-            st_actions.copy_(actions_host.reshape(n, self.flat, ACTION_DIM), non_blocking=True)
-            uploaded.record(copy_stream)
-        main.wait_event(uploaded)
-        self.codes_slots.copy_(st_codes, non_blocking=True)
-        self.actions_slots.copy_(st_actions, non_blocking=True)
-        consumed.record(main)
+        with torch.cuda.stream(st["stream"]):
+            st["stream"].wait_event(st["read"][sset])    # the last launch that read this set has finished
+            codes.copy_(codes_host.reshape(n, self.flat, CODE_DIM), non_blocking=True)
+            actions.copy_(actions_host.reshape(n, self.flat, ACTION_DIM), non_blocking=True)
+            st["uploaded"][sset].record(st["stream"])
+        main.wait_event(st["uploaded"][sset])
         if self.use_graph and self.reduce_fn is None:
-            self._replay(True, n)
-            return
-        for slot in range(n):
-            for fn, grad in self._segments(True, slot):
-                fn()
-                if grad is not None:
-                    self.reduce_fn(grad)
+            self._replay(True, n, sset)
+        else:
+            for slot in range(n):
+                for fn, grad in self._segments(True, slot, sset):
+                    fn()
+                    if grad is not None:
+                        self.reduce_fn(grad)
+        st["read"][sset].record(main)
 
     def _check_bindings(self):
         if self.g_flat.data_ptr() != self.decoder.flat_parameters().data_ptr() or \

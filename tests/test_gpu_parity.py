@@ -433,6 +433,33 @@ def test_multi_step_graph_is_bitwise_single_steps():
     assert outs[0][2] == outs[1][2] and outs[0][3] == outs[1][3]
 
 
+def test_uploads_from_pinned_host_memory_equal_resident_inputs():
+    """GanTrainer.step_many_from_host (fresh batch per step from pinned host memory, two alternating slot sets, upload
+    on a copy stream) against step_many on the same batches already on the device: bit-identical parameters and
+    losses over three launches (the second and third exercise both slot sets and the read-before-overwrite events)."""
+    from ndivplanning_amd.trainer import GanTrainer
+    spl, batch, k = 3, 8, 6
+    launches = [[O.synthetic_batch(40 + 3 * j + i, batch, k, steps=1) for i in range(spl)] for j in range(3)]
+    outs = []
+    for mode in ("resident", "host"):
+        g, d = O.init_params(0, 2)
+        dec, dis = _load_modules(g, d, 2)
+        tr = GanTrainer(dec, dis, flat=batch * 7, num_sample=k, steps_per_launch=spl, noise_seed=5)
+        for batches in launches:
+            codes = torch.stack([b[0] for b in batches])
+            actions = torch.stack([b[1] for b in batches])
+            if mode == "resident":
+                tr.step_many(codes.to(DEV), actions.to(DEV), None)
+            else:
+                tr.step_many_from_host(codes.pin_memory(), actions.pin_memory())
+        torch.cuda.synchronize()
+        outs.append((tr.g_flat.clone(), tr.d_flat.clone(), tr.losses(), tr.pop_loss_sums()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][2] == outs[1][2] and outs[0][3] == outs[1][3]
+    with pytest.raises(ValueError):
+        tr.step_many_from_host(torch.zeros(spl, batch * 7, 256), torch.zeros(spl, batch * 7, 4))   # not pinned
+
+
 # (64, 6): config 2, phase A with paired real tiles (168 tiles); (52, 6): the same form with a ragged last tile
 # (M = 2184, 138 tiles); (25, 6): one real tile per helper workgroup (66 tiles); (72, 6): stacked passes (189 tiles)
 # (128, 6): k_wgrad[G] with per-job chunk counts beside k_wgrad[D] with uniform ones (>= 16,384 rows)
