@@ -48,6 +48,12 @@ __device__ int g_stamp_kernel = 0;   // which kernel flushes: 1 k_g_fwd, 2 k_d, 
 #define NDP_STAMP_FLUSH(n, id) do { } while (0)
 #endif
 
+// -DNDP_PLAIN_KERNARGS: ablation of load_kernargs (ndp_device.h) in the phase kernels (27.5 vs 27.9 us for phase A)
+#ifdef NDP_PLAIN_KERNARGS
+constexpr bool kFastKernargs = false;
+#else
+constexpr bool kFastKernargs = true;
+#endif
 constexpr int CODE = 256;
 constexpr int ADIM = 4;
 constexpr int TAILLD = 16;   // LDS row stride of the narrow "tail" inputs (noise / action)
@@ -736,7 +742,7 @@ template <bool PK, int RG, bool SPLIT, bool PAIR>
 __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseAArgs a_segment) {
   // one workgroup per CU (RG = 96): nothing hides the argument loads, read them in one round trip (load_kernargs);
   // with several workgroups per CU the registers that costs are worth more
-  const PhaseAArgs a = RG >= 96 ? load_kernargs<PhaseAArgs>() : a_segment;
+  const PhaseAArgs a = (RG >= 96 && kFastKernargs) ? load_kernargs<PhaseAArgs>() : a_segment;
   constexpr int R = 16;
   constexpr int DR = (SPLIT && !PAIR) ? R : 2 * R;   // D rows the LDS regions are sized for
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -931,7 +937,7 @@ constexpr int phase_b_lds_floats(bool pre) {
 // is better spent on residency.
 template <bool PK, int RG, bool PRE>
 __global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseBArgs a_segment) {
-  const PhaseBArgs a = RG >= 96 ? load_kernargs<PhaseBArgs>() : a_segment;   // see k_phase_a
+  const PhaseBArgs a = (RG >= 96 && kFastKernargs) ? load_kernargs<PhaseBArgs>() : a_segment;   // see k_phase_a
   constexpr int R = 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XC = smem;                  // 16 x 260: code tile -> D.h3 / dY3 -> G.h4 / dY4
@@ -1044,19 +1050,22 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseB
   __syncthreads();
   NDP_STAMP(4);
   // dLoss/d action_hat = D.dY1 . W1[:, 0:4] (+ NDiv gradient) -> DA and dy5
-  if (threadIdx.x < R * ADIM) {
-    const int i = threadIdx.x >> 2, j = threadIdx.x & 3;
+  {
+    // all 256 threads: (row i, action column j, quarter `part` of the 64 terms), quarters added by two shuffles
+    // (one wave of 64 threads doing 64-term dot products was 0.9 us of a 21 us kernel)
+    const int i = threadIdx.x >> 4, j = (threadIdx.x >> 2) & 3, part = threadIdx.x & 3;
     const int64_t row = row0 + i;
+    const float ng = (part == 0 && row < a.m && a.nd_grad != nullptr) ? a.nd_grad[row * ADIM + j] : 0.f;
     float s = 0.f;
-#pragma unroll 8
-    for (int o = 0; o < 64; ++o) s = fmaf(B2[i * 68 + o], W1A[o * 4 + j], s);
-    if (row < a.m) {
-      if (a.nd_grad != nullptr) s += a.nd_grad[row * ADIM + j];
-    } else {
-      s = 0.f;
+#pragma unroll
+    for (int o = 16 * part; o < 16 * part + 16; ++o) s = fmaf(B2[i * 68 + o], W1A[o * 4 + j], s);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (part == 0) {
+      s = row < a.m ? s + ng : 0.f;
+      DA[i * ADIM + j] = s;
+      a.dy5[row * ADIM + j] = s;
     }
-    DA[threadIdx.x] = s;
-    a.dy5[row * ADIM + j] = s;
   }
   __syncthreads();
   NDP_STAMP(5);
@@ -1499,10 +1508,9 @@ __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& 
 }
 
 template <bool P2P>
-__global__ __launch_bounds__(kThreads) void k_reduce_adam(ReduceArgs a_segment) {
-  // single GPU: the arguments in one round trip (load_kernargs; the kernel is ~5 us, five serial scalar-cache
-  // misses were a third of it).  The exchanging variant indexes its peer table by rank and keeps the plain form.
-  const ReduceArgs a = P2P ? a_segment : load_kernargs<ReduceArgs>();
+__global__ __launch_bounds__(kThreads) void k_reduce_adam(ReduceArgs a) {
+  // (load_kernargs was tried here too: rocprofv3 averages 6.14 / 5.23 us against 5.51 / 5.45 us plain for the G / D
+  // launch -- every thread of 330 short-lived workgroups copying the struct costs more than the scalar misses do)
   __shared__ float sh[8];
   const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   const bool live = p < a.n;
