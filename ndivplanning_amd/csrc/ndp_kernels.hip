@@ -597,178 +597,157 @@ __device__ __forceinline__ void store_segment_sums(const float* dY, int ld, floa
 }
 
 // ================================================================ fused row-tile kernels of the step
-// Phase A (train_gan.py:165-183) for one 16-row tile in ONE workgroup: G forward, then D on
-// the real and the fake rows (stacked: 32 LDS rows, one stream of D's weights), BCE, backward
-// data path.  Versus k_g_fwd + k_d<1,2>: one launch and one input-tile load less, action_hat
-// goes from G to D through LDS.  LDS regions are reused as the data dies (78 KB -> 2 workgroups
-// per CU):  XC code tile x2 -> later D.h3 | B1 G.h1, G.h3 -> D.h2 | B2 G.h2 -> D.h1 | B3 G.h4
+// Phase A (train_gan.py:165-183): G forward, D on the fake and on the real rows, BCE, D's backward data path, in one
+// launch of two kinds of workgroups, each on one 16-row tile whose activations never leave LDS:
+//   role 0 (blocks 0 .. ntiles-1)   tile t of the M = FLAT*K generated rows: G fc1..fc5 (draws the noise), then D on
+//                                   the 16 fake rows (action_hat goes from G to D through LDS), loss, D backward;
+//   role 1 (blocks ntiles ..)       D on the REAL rows.  The reference feeds D K copies of every (action, code) pair
+//                                   (repeat_interleave, train_gan.py:140-156: action_unsqueeze / codes_unsqueeze), so the
+//                                   K rows of a FLAT row have identical logits and identical gradients.  They are
+//                                   computed once: role 1 runs over the FLAT distinct rows and weights each with K --
+//                                   dLoss/dlogit and the BCE term are multiplied by K, everything downstream (deltas,
+//                                   weight-gradient sums) is linear in them.  Same sums as the reference's, K equal
+//                                   terms added as one product; 1/K of the real pass' rows through D, its activations
+//                                   and deltas for k_wgrad 1/K of the bytes.
+// The real pass does not depend on G, so its workgroups run beside the others from the start.
+// LDS regions are reused as the data dies:  XC code tile -> D.h3 / dY3 | B1 G.h1, G.h3 -> D.h2 / dY2 | B2 G.h2 ->
+// D.h1 / dY1 | B3 G.h4.
 struct PhaseAArgs {
   GNet g; DNet d;
-  const float* code; int code_rep;          // [flat x 256], row r uses code[r / code_rep]
+  const float* code; int code_rep;          // [flat x 256], generated row r uses code[r / code_rep] (code_rep = K)
   const float* noise;                        // [m x nz] input, or null when noise_out != null
   float* noise_out; uint64_t noise_seed; const int32_t* noise_step;
-  const float* actions; int action_rep;      // ground-truth actions [flat x 4]
-  int64_t m, mpad;
-  float inv_m;
+  const float* actions;                      // ground-truth actions [flat x 4], one per FLAT row
+  int64_t m, mpad;                           // generated (fake) rows, padded
+  int64_t flat, rpad;                        // distinct real rows (m / K), padded
+  float inv_m;                               // BCE mean scale: 1 / global M
+  float real_scale;                          // K: what one real row stands for
   float *gh1, *gh2, *gh3, *gh4;              // G activations out [mpad x .]
   float* action_hat;                         // [m x 4] out
-  float *h1, *h2, *h3, *dy1, *dy2, *dy3, *dl, *xa;   // D buffers for k_wgrad [2*mpad x .]
-  float* loss_partials;                      // [ntiles]
-  float* dy1seg; int seg_s, seg_entries;     // segment sums of dY1 (real + fake) [seg_entries x 64]
+  float *h1, *h2, *h3, *dy1, *dy2, *dy3, *dl, *xa;   // D buffers for k_wgrad [(rpad + mpad) x .]: real rows, then fake rows
+  float* loss_partials;                      // [gridDim.x]
+  float* dy1seg; int seg_s, seg_entries;     // fc1 code-column operand of k_wgrad [(seg_entries + rpad) x 64]: per-tile
+                                             // segment sums of the fake pass' dY1, then the real rows' dY1 as they are
 };
 
 // Small weights every tile needs -- G.fc5 [4 x 256] + bias, D.fc4 [256] + bias -- are staged in LDS once per workgroup:
 // read straight from global inside the narrow (VALU) layers they were a serial chain of L2 round trips (stamps: fc5
-// 0.9 us, D fc4 + loss 1.2 us, 4.9 us for the 64-step dA loop at large M).  The split variants have LDS to spare and
-// get a region of their own; the stacked variant must stay under 80 KB (two workgroups per CU) and parks fc5 in the
-// upper half of B2 (free during G's forward) and fc4 in B3 once G.h4 is dead.
+// 0.9 us, D fc4 + loss 1.2 us, 4.9 us for the 64-step dA loop at large M).
 constexpr int kSW5 = 1024 + 8, kSW4 = 256 + 8;
-constexpr int phase_a_lds_floats(bool one_pass, bool split = true) {
-  return (one_pass ? 16 : 32) * (260 + TAILLD + 132 + 68 + 2) + 16 * 260 + 16 * 4 + 8 + (split ? kSW5 + kSW4 : 0);
+constexpr int phase_a_lds_floats() {
+  return 16 * (260 + TAILLD + 132 + 68 + 2) + 16 * 260 + 16 * 4 + 8 + kSW5 + kSW4;
 }
 
-// One D pass handled by a workgroup: which global pass (0 = real, 1 = fake), which 16-row tile.
-struct TilePass { int gp; int tile; int64_t row0; bool valid; };
-
-// D forward + BCE + D backward data path on NP stacked 16-row passes whose inputs are in XC (codes) and
-// XT (actions) and whose fc1 weights `dw1` are already in flight.  SEG_COMBINED: both passes belong to the
-// same tile and their dY1 segment sums are added (stacked phase A); otherwise every pass writes the sums
-// of its own tile into its global pass' half of the [2E] buffer.
-template <int NP, bool PK, int RG, bool SEG_COMBINED>
-__device__ __forceinline__ void phase_a_d_part(const PhaseAArgs& a, const TilePass (&pass)[NP], int ntiles,
+// D forward + BCE + D backward data path on one 16-row tile whose inputs are in XC (codes) and XT (actions) and whose
+// fc1 weights `dw1` are already in flight.  real: the tile holds distinct real rows (weight real_scale each, stored
+// at row offset 0); otherwise fake rows (stored behind the rpad real rows).
+template <bool PK, int RG>
+__device__ __forceinline__ void phase_a_d_part(const PhaseAArgs& a, bool real, int tile, int ntiles,
                                                FwdW<256, 64, 4, PK, RG>& dw1, float* XC, float* XT, float* B1,
-                                               float* B2, float* L, float* DL, float* red, const float* W4S,
+                                               float* B2, float* L, float* DL, const float* W4S,
                                                unsigned long long* stamp_lds_) {
   constexpr int R = 16;
-  constexpr int DR = R * NP;
   const DNet& d = a.d;
   (void)stamp_lds_;
+  const int64_t row0 = (int64_t)tile * R;
+  const int64_t nvalid = real ? a.flat : a.m;
+  const int64_t g0 = (real ? 0 : a.rpad) + row0;                  // row of this tile in the buffers k_wgrad reads
   // each layer's first weight fragments are issued inside the previous layer's k-loop (FwdW::preload_slice)
   FwdW<64, 128, 4, PK, RG> dw2;
   dw2.bind(PK ? d.pf2 : d.w2, 64, d.b2, nullptr, 0);
   NDP_STAMP(10);
-  layer_fwd_run<NP, 256, 64, ACT_LRELU, 4, PK>(dw1, XC, 260, B2, 68, XT, TAILLD, dw2); // D.h1 -> B2
+  layer_fwd_run<1, 256, 64, ACT_LRELU, 4, PK>(dw1, XC, 260, B2, 68, XT, TAILLD, dw2);  // D.h1 -> B2
   NDP_STAMP(11);
   __syncthreads();
   NDP_STAMP(3);
   FwdW<128, 256, 4, PK, RG> dw3;
   dw3.bind(PK ? d.pf3 : d.w3, 128, d.b3, nullptr, 0);
-  layer_fwd_run<NP, 64, 128, ACT_LRELU, 4, PK>(dw2, B2, 68, B1, 132, nullptr, 0, dw3); // D.h2 -> B1
+  layer_fwd_run<1, 64, 128, ACT_LRELU, 4, PK>(dw2, B2, 68, B1, 132, nullptr, 0, dw3);  // D.h2 -> B1
   __syncthreads();
   // (the backward's first layer too: its fragments wait in registers through the narrow fc4 / loss stages)
   DgW<128, 256, PK, RG> dg3;
   dg3.bind(PK ? d.pg3 : d.w3, 128);
-  layer_fwd_run<NP, 128, 256, ACT_LRELU, 4, PK>(dw3, B1, 132, XC, 260, nullptr, 0, dg3);   // D.h3 -> XC (code tile is dead)
+  layer_fwd_run<1, 128, 256, ACT_LRELU, 4, PK>(dw3, B1, 132, XC, 260, nullptr, 0, dg3); // D.h3 -> XC (code tile is dead)
   __syncthreads();
   NDP_STAMP(4);
-  layer_fwd_narrow<NP, 256, 1>(XC, 260, W4S, W4S + 256, L, 1);
+  layer_fwd_narrow<1, 256, 1>(XC, 260, W4S, W4S + 256, L, 1);
   __syncthreads();
   float lsum = 0.f;
-  if (threadIdx.x < DR) {
-    const int ps = threadIdx.x / R;
-    const TilePass q = (NP == 1 || ps == 0) ? pass[0] : pass[NP - 1];
-    const int64_t row = q.row0 + (threadIdx.x - ps * R);
-    const float target = q.gp == 0 ? 1.f : 0.f;                  // real: ones, fake: zeros (train_gan.py:174-181)
+  if (threadIdx.x < R) {
+    const int64_t row = row0 + threadIdx.x;
+    const float target = real ? 1.f : 0.f;                        // real: ones, fake: zeros (train_gan.py:174-181)
+    const float weight = real ? a.real_scale : 1.f;               // a real row stands for K identical rows
     const float x = L[threadIdx.x];
     float dl = 0.f;
-    if (row < a.m) {
-      lsum = fmaxf(x, 0.f) - x * target + log1pf(expf(-fabsf(x)));
-      dl = (1.f / (1.f + expf(-x)) - target) * a.inv_m;
+    if (row < nvalid) {
+      lsum = weight * (fmaxf(x, 0.f) - x * target + log1pf(expf(-fabsf(x))));
+      dl = weight * ((1.f / (1.f + expf(-x)) - target) * a.inv_m);
     }
     DL[threadIdx.x] = dl;
-    if (q.valid) a.dl[(int64_t)q.gp * a.mpad + row] = dl;
+    a.dl[g0 + threadIdx.x] = dl;
   }
-  if (threadIdx.x < 64) {               // the rows' losses all sit in wave 0 (DR <= 32): no block-wide reduction
+  if (threadIdx.x < 64) {               // the rows' losses all sit in wave 0: no block-wide reduction
     const float tot = wave_sum(lsum);
     if (threadIdx.x == 0) a.loss_partials[blockIdx.x] = tot;
   }
   NDP_STAMP(5);
-#pragma unroll
-  for (int ps = 0; ps < NP; ++ps) {
-    if (!pass[ps].valid) continue;
-    const int64_t g0 = (int64_t)pass[ps].gp * a.mpad + pass[ps].row0;
-    store_tile<1, 64>(a.h1 + g0 * 64, 64, B2 + ps * R * 68, 68);
-    store_tile<1, 128>(a.h2 + g0 * 128, 128, B1 + ps * R * 132, 132);
-    store_tile<1, 256>(a.h3 + g0 * 256, 256, XC + ps * R * 260, 260);
-  }
-  if (threadIdx.x < DR) {
-    const int ps = threadIdx.x / R;
-    const TilePass q = (NP == 1 || ps == 0) ? pass[0] : pass[NP - 1];
-    const int64_t gr = (int64_t)q.gp * a.mpad + q.row0 + (threadIdx.x - ps * R);
-    if (q.valid) *reinterpret_cast<f32x4*>(a.xa + gr * 4) = *reinterpret_cast<const f32x4*>(XT + threadIdx.x * TAILLD);
-  }
+  store_tile<1, 64>(a.h1 + g0 * 64, 64, B2, 68);
+  store_tile<1, 128>(a.h2 + g0 * 128, 128, B1, 132);
+  store_tile<1, 256>(a.h3 + g0 * 256, 256, XC, 260);
+  if (threadIdx.x < R)
+    *reinterpret_cast<f32x4*>(a.xa + (g0 + threadIdx.x) * 4) = *reinterpret_cast<const f32x4*>(XT + threadIdx.x * TAILLD);
   __syncthreads();
   NDP_STAMP(6);
-  layer_dgrad_narrow<NP, 256, 1, ACT_LRELU>(DL, 1, W4S, XC, 260);                      // XC := dY3
+  layer_dgrad_narrow<1, 256, 1, ACT_LRELU>(DL, 1, W4S, XC, 260);                       // XC := dY3
   __syncthreads();
   DgW<64, 128, PK, RG> dg2;
   dg2.bind(PK ? d.pg2 : d.w2, 64);
-  layer_dgrad_run<NP, 128, 256, ACT_LRELU, PK>(dg3, XC, 260, B1, 132, dg2);            // B1 := dY2
+  layer_dgrad_run<1, 128, 256, ACT_LRELU, PK>(dg3, XC, 260, B1, 132, dg2);             // B1 := dY2
   __syncthreads();
   NDP_STAMP(7);
-  layer_dgrad_run<NP, 64, 128, ACT_LRELU, PK>(dg2, B1, 132, B2, 68);                   // B2 := dY1
+  layer_dgrad_run<1, 64, 128, ACT_LRELU, PK>(dg2, B1, 132, B2, 68);                    // B2 := dY1
   __syncthreads();
-  // segment sums of dY1 for the K-deduplicated fc1 weight gradient
-  if (SEG_COMBINED) {
-    store_segment_sums<64, NP>(B2, 68, a.dy1seg, pass[0].row0, a.code_rep, a.seg_s, a.seg_entries, pass[0].tile, ntiles);
-  } else {
-#pragma unroll
-    for (int ps = 0; ps < NP; ++ps)
-      if (pass[ps].valid)
-        store_segment_sums<64, 1>(B2 + ps * R * 68, 68, a.dy1seg + (size_t)pass[ps].gp * a.seg_entries * 64,
-                                  pass[ps].row0, a.code_rep, a.seg_s, a.seg_entries, pass[ps].tile, ntiles);
-  }
-#pragma unroll
-  for (int ps = 0; ps < NP; ++ps) {
-    if (!pass[ps].valid) continue;
-    const int64_t g0 = (int64_t)pass[ps].gp * a.mpad + pass[ps].row0;
-    store_tile<1, 64>(a.dy1 + g0 * 64, 64, B2 + ps * R * 68, 68);
-    store_tile<1, 128>(a.dy2 + g0 * 128, 128, B1 + ps * R * 132, 132);
-    store_tile<1, 256>(a.dy3 + g0 * 256, 256, XC + ps * R * 260, 260);
-  }
+  // fc1's code-column weight gradient runs K-deduplicated: the fake rows of a tile that share a FLAT row (same code)
+  // are pre-summed here; a real row is its FLAT row
+  if (real) store_tile<1, 64>(a.dy1seg + ((size_t)a.seg_entries + row0) * 64, 64, B2, 68);
+  else store_segment_sums<64, 1>(B2, 68, a.dy1seg, row0, a.code_rep, a.seg_s, a.seg_entries, tile, ntiles);
+  store_tile<1, 64>(a.dy1 + g0 * 64, 64, B2, 68);
+  store_tile<1, 128>(a.dy2 + g0 * 128, 128, B1, 132);
+  store_tile<1, 256>(a.dy3 + g0 * 256, 256, XC, 260);
 }
 
-// RG = VGPR budget of each weight prefetch ring: 96 keeps a lone workgroup per CU streaming at
-// small M; 32 with a 256-register cap lets two workgroups share a CU at large M.
-// SPLIT (small M, fewer tiles than CUs): the D step's real pass does not depend on G, so it runs
-// in workgroups of its own (role 1, blocks ntiles..) on the CUs that have no tile, beside the
-// G-forward + D(fake) workgroups (role 0, blocks 0..ntiles-1): the critical path per tile drops
-// from G + 32 D rows to G + 16 D rows.  PAIR: a role-1 workgroup stacks TWO real tiles (t, t + nh)
-// on one stream of D's weights, so that ntiles + ceil(ntiles / 2) <= 256 workgroups get a CU each
-// (the launch asks for more than half a CU's LDS to keep a second workgroup out) instead of 2 x ntiles
-// doubling up and slowing the role-0 workgroups.  With more tiles than CUs the stacked form (!SPLIT:
-// 16 real + 16 fake rows of the same tile in one workgroup) is the better use of a CU.
-template <bool PK, int RG, bool SPLIT, bool PAIR>
-__global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseAArgs a_segment) {
+// RG = VGPR budget of each weight prefetch ring: 96 keeps a lone workgroup per CU streaming (grids of up to 256
+// workgroups); 32 with a tighter register cap lets several workgroups share a CU at large M.
+template <bool PK, int RG>
+__global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 3)) void k_phase_a(PhaseAArgs a_segment) {
   // one workgroup per CU (RG = 96): nothing hides the argument loads, read them in one round trip (load_kernargs);
   // with several workgroups per CU the registers that costs are worth more
   const PhaseAArgs a = (RG >= 96 && kFastKernargs) ? load_kernargs<PhaseAArgs>() : a_segment;
   constexpr int R = 16;
-  constexpr int DR = (SPLIT && !PAIR) ? R : 2 * R;   // D rows the LDS regions are sized for
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* XC = smem;                  // DR x 260
-  float* XT = XC + DR * 260;         // DR x 16
-  float* B1 = XT + DR * TAILLD;      // DR x 132
-  float* B2 = B1 + DR * 132;         // DR x 68
-  float* B3 = B2 + DR * 68;          // 16 x 260
-  float* A = B3 + 16 * 260;          // 16 x 4
-  float* L = A + 16 * 4;             // DR
-  float* DL = L + DR;                // DR
-  float* red = DL + DR;              // 8
-  float* W5S = SPLIT ? red + 8 : B2 + 16 * 68;       // G.fc5 weights [4][256] + bias (kSW5 floats)
-  float* W4S = SPLIT ? red + 8 + kSW5 : B3;          // D.fc4 weights [256] + bias    (kSW4 floats)
+  float* XC = smem;                  // 16 x 260
+  float* XT = XC + R * 260;          // 16 x 16
+  float* B1 = XT + R * TAILLD;       // 16 x 132
+  float* B2 = B1 + R * 132;          // 16 x 68
+  float* B3 = B2 + R * 68;           // 16 x 260
+  float* A = B3 + R * 260;           // 16 x 4
+  float* L = A + R * 4;              // 16
+  float* DL = L + R;                 // 16
+  float* red = DL + R;               // 8
+  float* W5S = red + 8;              // G.fc5 weights [4][256] + bias (kSW5 floats)
+  float* W4S = W5S + kSW5;           // D.fc4 weights [256] + bias    (kSW4 floats)
   const int ntiles = (int)(a.mpad / R);
-  const int role = SPLIT ? (int)((int)blockIdx.x >= ntiles) : 0;          // SPLIT: 0 = G + D(fake), 1 = D(real)
+  const bool real = (int)blockIdx.x >= ntiles;                    // role 1: a tile of distinct real rows
   const GNet& g = a.g;
   const DNet& d = a.d;
   NDP_STAMP_DECL;
   NDP_STAMP(0);
 
   FwdW<256, 64, 4, PK, RG> dw1;
-  if (!SPLIT || role == 0) {
+  if (!real) {
     const int tile = (int)blockIdx.x;
     const int64_t row0 = (int64_t)tile * R;
-    // ---------------- G forward (rows 0..15 of the regions)
+    // ---------------- G forward
     FwdW<256, 128, 2, PK, RG> gw1;
     gw1.preload(PK ? g.pf1 : g.w1, g.ld1, g.b1, g.w1 + CODE, g.nz);
     const f32x4 w5r = *reinterpret_cast<const f32x4*>(g.w5 + 4 * threadIdx.x);
@@ -778,9 +757,8 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseA
       const int i = idx >> 6, k = 4 * (idx & 63);
       const int64_t row = row0 + i;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < a.m) v = *reinterpret_cast<const f32x4*>(a.code + (row / a.code_rep) * CODE + k);
+      if (row < a.m) v = *reinterpret_cast<const f32x4*>(a.code + (size_t)((uint32_t)row / (uint32_t)a.code_rep) * CODE + k);
       *reinterpret_cast<f32x4*>(XC + i * 260 + k) = v;
-      if (!SPLIT) *reinterpret_cast<f32x4*>(XC + (R + i) * 260 + k) = v;       // the fake pass' copy
     }
     NDP_STAMP(25);
     for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {
@@ -799,10 +777,8 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseA
     }
     *reinterpret_cast<f32x4*>(W5S + 4 * threadIdx.x) = w5r;
     if (threadIdx.x < 4) W5S[1024 + threadIdx.x] = b5r;
-    if (SPLIT) {
-      W4S[threadIdx.x] = w4r;
-      if (threadIdx.x == 0) W4S[256] = b4r;
-    }
+    W4S[threadIdx.x] = w4r;
+    if (threadIdx.x == 0) W4S[256] = b4r;
     NDP_STAMP(26);
     __syncthreads();
     NDP_STAMP(1);
@@ -839,25 +815,12 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseA
     NDP_STAMP(22);
     layer_fwd_narrow<1, 256, 4>(B3, 260, W5S, W5S + 1024, A, 4);                          // action_hat -> A
     NDP_STAMP(23);
-    if (!SPLIT) {
-      // real actions -> XT rows 0..15 (the noise there is dead), zero pad
-      for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {
-        const int i = idx / TAILLD, t = idx % TAILLD;
-        const int64_t row = row0 + i;
-        XT[idx] = (row < a.m && t < ADIM) ? a.actions[(row / a.action_rep) * ADIM + t] : 0.f;
-      }
-    }
     __syncthreads();
     NDP_STAMP(2);
-    if (!SPLIT) {                                                                         // G.h4 (B3) is dead: fc4 moves in
-      W4S[threadIdx.x] = w4r;
-      if (threadIdx.x == 0) W4S[256] = b4r;
-    }
-    constexpr int FK = SPLIT ? 0 : 1;                                                     // LDS pass slot of the fake rows
-    for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {                      // fake actions -> XT
+    for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {                      // fake actions -> XT (the noise is dead)
       const int i = idx / TAILLD, t = idx % TAILLD;
       const int64_t row = row0 + i;
-      XT[(FK * R + i) * TAILLD + t] = (row < a.m && t < ADIM) ? A[i * 4 + t] : 0.f;
+      XT[idx] = (row < a.m && t < ADIM) ? A[i * 4 + t] : 0.f;
     }
     if (threadIdx.x < R) {
       const int64_t row = row0 + threadIdx.x;
@@ -866,45 +829,31 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 2)) void k_phase_a(PhaseA
     }
     __syncthreads();
     NDP_STAMP(9);
-    // ---------------- D on the fake rows (split) or on real + fake rows (stacked)
-    if (SPLIT) {
-      const TilePass pass[1] = {{1, tile, row0, true}};
-      phase_a_d_part<1, PK, RG, false>(a, pass, ntiles, dw1, XC, XT, B1, B2, L, DL, red, W4S, NDP_STAMP_PTR);
-    } else {
-      const TilePass pass[2] = {{0, tile, row0, true}, {1, tile, row0, true}};
-      phase_a_d_part<2, PK, RG, true>(a, pass, ntiles, dw1, XC, XT, B1, B2, L, DL, red, W4S, NDP_STAMP_PTR);
-    }
+    // ---------------- D on the fake rows
+    phase_a_d_part<PK, RG>(a, false, tile, ntiles, dw1, XC, XT, B1, B2, L, DL, W4S, NDP_STAMP_PTR);
   } else {
-    // ---------------- SPLIT, role 1: the real pass of one tile, or of two stacked tiles (PAIR)
-    constexpr int NP = PAIR ? 2 : 1;
-    const int h = (int)blockIdx.x - ntiles, nh = (int)gridDim.x - ntiles;
-    TilePass pass[NP];
-#pragma unroll
-    for (int ps = 0; ps < NP; ++ps) {
-      const int t = h + ps * nh;
-      pass[ps].valid = t < ntiles;
-      pass[ps].gp = 0;
-      pass[ps].tile = pass[ps].valid ? t : 0;
-      pass[ps].row0 = pass[ps].valid ? (int64_t)t * R : a.mpad;     // rows >= m: zero inputs, zero loss, no stores
-    }
+    // ---------------- role 1: D on one tile of the distinct real rows
+    const int tile = (int)blockIdx.x - ntiles;
+    const int64_t row0 = (int64_t)tile * R;
     dw1.preload(PK ? d.pf1 : d.w1 + ADIM, 260, d.b1, d.w1, ADIM);
     W4S[threadIdx.x] = d.w4[threadIdx.x];
     if (threadIdx.x == 0) W4S[256] = d.b4[0];
-    for (int idx = threadIdx.x; idx < NP * R * 64; idx += kThreads) {
+    for (int idx = threadIdx.x; idx < R * 64; idx += kThreads) {
       const int i = idx >> 6, k = 4 * (idx & 63);
-      const int64_t row = ((NP == 1 || i < R) ? pass[0].row0 : pass[NP - 1].row0) + (i % R);
+      const int64_t row = row0 + i;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < a.m) v = *reinterpret_cast<const f32x4*>(a.code + (row / a.code_rep) * CODE + k);
+      if (row < a.flat) v = *reinterpret_cast<const f32x4*>(a.code + row * CODE + k);
       *reinterpret_cast<f32x4*>(XC + i * 260 + k) = v;
     }
-    for (int idx = threadIdx.x; idx < NP * R * TAILLD; idx += kThreads) {
+    for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {
       const int i = idx / TAILLD, t = idx % TAILLD;
-      const int64_t row = ((NP == 1 || i < R) ? pass[0].row0 : pass[NP - 1].row0) + (i % R);
-      XT[idx] = (row < a.m && t < ADIM) ? a.actions[(row / a.action_rep) * ADIM + t] : 0.f;
+      const int64_t row = row0 + i;
+      XT[idx] = (row < a.flat && t < ADIM) ? a.actions[row * ADIM + t] : 0.f;
     }
     __syncthreads();
-    phase_a_d_part<NP, PK, RG, false>(a, pass, ntiles, dw1, XC, XT, B1, B2, L, DL, red, W4S, NDP_STAMP_PTR);
+    phase_a_d_part<PK, RG>(a, true, tile, ntiles, dw1, XC, XT, B1, B2, L, DL, W4S, NDP_STAMP_PTR);
   }
+  (void)red;
   NDP_STAMP(8);
   NDP_STAMP_FLUSH(32, 5);
 }
@@ -1141,8 +1090,9 @@ struct WgradJob {
   // of a 16-row tile that share a FLAT row (same code) are pre-summed by the phase kernel, real and
   // fake pass together -- so the job runs over rows = ntiles*seg_s entries instead of all M rows;
   // entry e = tile*seg_s + s pairs with code row (16*tile)/seg_k + s.  rows == 0: plain job.
-  int rows, seg_s, seg_k;
-  int seg_wrap;        // entries per pass when real and fake segment sums are kept apart (0: one set)
+  int rows, seg, seg_s, seg_k;   // rows != 0: the job's own row space; seg: rows are segment-sum entries
+  int seg_wrap;        // seg jobs: entries from seg_wrap on are plain rows -- entry seg_wrap + f pairs with code row f
+                       // (the deduplicated real pass of the D step, k_phase_a); 0: none
   int nchunks;         // row chunks (= slabs) of THIS job, <= WgradArgs::nchunks: the full 64 x 64 jobs take more
 };
 constexpr int kMaxJobs = 28;
@@ -1188,8 +1138,8 @@ __device__ __forceinline__ void wgrad_block(const WgradJob& jb, int rbeg, int re
   // consumed; narrow operands are loaded from a clamped column and zeroed by a select): a
   // branch around a load makes hipcc fall back to s_waitcnt vmcnt(0) inside the loop.
   constexpr int PF = NDP_WGRAD_PFG;
-  const bool plain_b = jb.rows == 0 && jb.b_rowdiv == 1 && jb.b_rowmod == 0x7fffffff;   // uniform per workgroup
-  const bool seg_b = jb.rows != 0;
+  const bool seg_b = jb.seg != 0;
+  const bool plain_b = !seg_b && jb.b_rowdiv == 1 && jb.b_rowmod == 0x7fffffff;         // uniform per workgroup
   const float b_inv = 1.0f / (float)(seg_b ? jb.seg_k : jb.b_rowdiv);
   const float s_inv = 1.0f / (float)(seg_b ? jb.seg_s : 1);
   const int nsteps = rend > rbeg ? (rend - rbeg) >> 4 : 0;
@@ -1219,7 +1169,8 @@ __device__ __forceinline__ void wgrad_block(const WgradJob& jb, int rbeg, int re
     int brow = row;
     if (seg_b) {
       // entry -> (tile, s) -> code row (16*tile)/K + s; exact divisions by reciprocal + fix-up
-      const int e = (jb.seg_wrap != 0 && row >= jb.seg_wrap) ? row - jb.seg_wrap : row;
+      const bool ident = jb.seg_wrap != 0 && row >= jb.seg_wrap;
+      const int e = ident ? 0 : row;
       int tile = (int)((float)e * s_inv);
       tile = tile * jb.seg_s > e ? tile - 1 : tile;
       tile = (tile + 1) * jb.seg_s <= e ? tile + 1 : tile;
@@ -1227,7 +1178,7 @@ __device__ __forceinline__ void wgrad_block(const WgradJob& jb, int rbeg, int re
       int f0 = (int)((float)x * b_inv);
       f0 = f0 * jb.seg_k > x ? f0 - 1 : f0;
       f0 = (f0 + 1) * jb.seg_k <= x ? f0 + 1 : f0;
-      brow = f0 + (e - tile * jb.seg_s);
+      brow = ident ? row - jb.seg_wrap : f0 + (e - tile * jb.seg_s);
     } else if (!plain_b) {
       const int x = row >= jb.b_rowmod ? row - jb.b_rowmod : row;
       int qd = (int)((float)x * b_inv);
