@@ -66,17 +66,28 @@ G_FWD = 128 * 258 + 64 * 128 + 128 * 64 + 256 * 128 + 4 * 256           # 83,200
 D_FWD = 64 * 260 + 128 * 64 + 256 * 128 + 256                            # 57,856
 D_DGRAD = 256 + 256 * 128 + 128 * 64                                     # 41,216
 G_DGRAD = 4 * 256 + 256 * 128 + 128 * 64 + 64 * 128                      # 50,176
-KERNEL_MACS_PER_ROW = {
-    "k_phase_a": G_FWD + 2 * (D_FWD + D_DGRAD),          # G forward + D(real), D(fake) forward/backward data path
-    "k_wgrad[D]": 2 * D_FWD,
-    "k_phase_b": D_FWD + D_DGRAD + 4 * 64 + G_DGRAD,     # D' forward/backward to action_hat + G backward data path
-    "k_wgrad[G]": G_FWD,
-}
-MACS_PER_ROW_STEP = 629760
-assert sum(KERNEL_MACS_PER_ROW.values()) == MACS_PER_ROW_STEP
-# kernels of the non-fused entry points (repeat D steps, module API); not part of the default step
-KERNEL_MACS_PER_ROW.update({"k_g_fwd": G_FWD, "k_d[2 pass fwd+bwd]": 2 * (D_FWD + D_DGRAD),
-                            "k_d[fwd+bwd]": D_FWD + D_DGRAD + 4 * 64, "k_g_bwd": G_DGRAD})
+MACS_PER_ROW_STEP = 629760       # the reference's step, autograd-minimal, per M-row
+
+
+def kernel_macs(k):
+    """MACs per M-row that each kernel EXECUTES.  `real` = share of the D step's real pass that runs: the reference
+    feeds D K identical copies of every real (action, code) pair (train_gan.py:140-156); k_phase_a / k_wgrad[D] run it
+    on the FLAT distinct rows, weighted K -- 1/K of the rows.  With real = 1 the table is SURVEY.md's 629,760."""
+    real = 1.0 / k
+    macs = {
+        "k_phase_a": G_FWD + (1 + real) * (D_FWD + D_DGRAD),  # G forward + D(fake), D(real) forward/backward data path
+        "k_wgrad[D]": (1 + real) * D_FWD,
+        "k_phase_b": D_FWD + D_DGRAD + 4 * 64 + G_DGRAD,      # D' forward/backward to action_hat + G backward data path
+        "k_wgrad[G]": G_FWD,
+    }
+    executed = sum(macs.values())
+    # kernels of the non-fused entry points (repeat D steps, module API); not part of the default step
+    macs.update({"k_g_fwd": G_FWD, "k_d[2 pass fwd+bwd]": 2 * (D_FWD + D_DGRAD),
+                 "k_d[fwd+bwd]": D_FWD + D_DGRAD + 4 * 64, "k_g_bwd": G_DGRAD})
+    return macs, executed
+
+
+assert abs(kernel_macs(1)[1] - MACS_PER_ROW_STEP) < 1e-6
 ENCODER_FLOP_PER_IMAGE = 622.3e6                          # SURVEY.md section 8d (311.2 M MAC)
 TRAJ, NZ = 8, 2
 
@@ -252,7 +263,12 @@ class Bench:
 
 
 def step_flops(m):
+    """FLOPs of the reference's step on m rows, whatever this implementation executes."""
     return 2.0 * MACS_PER_ROW_STEP * m
+
+
+def step_flops_executed(m, k):
+    return 2.0 * kernel_macs(k)[1] * m
 
 
 def workload_summary(batch, k, world, sec, steps, reps, extra=None):
@@ -262,13 +278,16 @@ def workload_summary(batch, k, world, sec, steps, reps, extra=None):
            "ms_per_step": round(1e3 * sec / steps, 5), "iterations_per_sec": round(iters, 2),
            "trajectories_per_sec": round(iters * batch * world, 1), "repeats": len(reps),
            "whole_step_tflops_per_gpu": round(step_flops(m) * iters / 1e12, 3),
-           "whole_step_frac_of_fp32_mfma_peak": round(step_flops(m) * iters / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
+           # the reference's step (629,760 MAC per row) per second against the fp32-MFMA peak ...
+           "whole_step_frac_of_fp32_mfma_peak": round(step_flops(m) * iters / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+           # ... and the MACs the kernels really execute (real pass of D on 1/K of the rows): matrix-pipe utilisation
+           "executed_frac_of_fp32_mfma_peak": round(step_flops_executed(m, k) * iters / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
     if extra:
         out.update(extra)
     return out
 
 
-def kernel_table(b, tr, m, reps=50):
+def kernel_table(b, tr, m, k, reps=50):
     """Per-kernel durations: HIP events around every launch, eager launches of the same step
     (every rank steps -- the exchange needs all of them -- rank 0 records)."""
     from ndivplanning_amd import _capi
@@ -283,9 +302,10 @@ def kernel_table(b, tr, m, reps=50):
     if b.rank == 0:
         timed = _capi.timing_collect()
         _capi.timing_enable(False)
+        table = kernel_macs(k)[0]
         for name, (ms, cnt) in timed.items():
             us = 1e3 * ms / max(cnt, 1)
-            macs = KERNEL_MACS_PER_ROW.get(name)
+            macs = table.get(name)
             kernels[name] = {"avg_us": round(us, 3), "launches_per_step": cnt / reps,
                              "tflops": round(2.0 * macs * m / (us * 1e-6) / 1e12, 3) if macs else None}
     tr.use_graph = saved
@@ -299,7 +319,7 @@ def large_m_point(b, batch, k, steps):
     sec, reps = b.timed(tr, steps, max(steps // 4, 8))
     m = batch * (TRAJ - 1) * k
     out = workload_summary(batch, k, 1, sec, steps, reps)
-    out["kernels"] = kernel_table(b, tr, m, reps=10)
+    out["kernels"] = kernel_table(b, tr, m, k, reps=10)
     del tr
     torch.cuda.empty_cache()
     return out
@@ -443,7 +463,7 @@ def main():
         elapsed, reps = b.timed(tr, args.steps, args.warmup)
         losses = tr.losses()
         hip_graph = bool(tr.use_graph)
-        kernels = kernel_table(b, tr, m)
+        kernels = kernel_table(b, tr, m, k)
         replicas_identical = replicas_in_lockstep(tr) if world > 1 else None
         if b.p2p is None:
             break
@@ -522,8 +542,9 @@ def main():
 
     iters_per_s = args.steps / elapsed
     value = iters_per_s * world
-    dom = max((n_ for n_ in kernels if KERNEL_MACS_PER_ROW.get(n_)), key=lambda n_: kernels[n_]["avg_us"] * kernels[n_]["launches_per_step"])
-    dom_flops = 2.0 * KERNEL_MACS_PER_ROW[dom] * m
+    table = kernel_macs(k)[0]
+    dom = max((n_ for n_ in kernels if table.get(n_)), key=lambda n_: kernels[n_]["avg_us"] * kernels[n_]["launches_per_step"])
+    dom_flops = 2.0 * table[dom] * m                     # what the kernel executes per launch
     achieved = dom_flops / (kernels[dom]["avg_us"] * 1e-6) / 1e12
     result = {
         "metric": "gan_train_steps_per_sec_traj8_batch64", "value": round(value, 2), "unit": "steps/s",
@@ -546,9 +567,13 @@ def main():
                      "traffic": PMC_HBM_BYTES_DEFAULT.get(dom) if (batch, k) == (64, 6) else None,
                      "traffic_source": PMC_SOURCE,
                      "algorithmic_flops_per_launch": dom_flops,
+                     "flops_note": "per-kernel figures count the MACs executed: D's real pass runs on the FLAT distinct "
+                                   "rows (1/K of what the reference feeds through D, train_gan.py:140-156)",
                      "whole_step": {"flops": step_flops(m),
                                     "tflops": round(step_flops(m) * iters_per_s / 1e12, 3),
-                                    "frac": round(step_flops(m) * iters_per_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)},
+                                    "frac": round(step_flops(m) * iters_per_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                    "flops_executed": step_flops_executed(m, k),
+                                    "frac_executed": round(step_flops_executed(m, k) * iters_per_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)},
                      "kernels": kernels},
     }
     if parity is not None:
