@@ -57,9 +57,9 @@ HBM_PEAK_GBS = 8000.0
 # gfx950 correction of MI355X_MICROARCH.md section HBM: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
 # bench.py cannot read PMC counters itself; the figure is reported only for the workload it was
 # measured on.
-PMC_HBM_BYTES_DEFAULT = {"k_phase_a": 33648969, "k_phase_b": 18605577, "k_wgrad[D]": 34128064,
-                         "k_wgrad[G]": 21473056}
-PMC_SOURCE = "profiles/r02_v9_pmc_hbm.csv (rocprofv3 --pmc, bytes per launch)"
+PMC_HBM_BYTES_DEFAULT = {"k_phase_a": 25406097, "k_phase_b": 18609673, "k_wgrad[D]": 18810131,
+                         "k_wgrad[G]": 21497248}
+PMC_SOURCE = "profiles/r02_v11_pmc_hbm.csv (rocprofv3 --pmc, bytes per launch)"
 
 # algorithmic MACs per M-row of each kernel (629,760 per row per step)
 G_FWD = 128 * 258 + 64 * 128 + 128 * 64 + 256 * 128 + 4 * 256           # 83,200
@@ -400,8 +400,9 @@ def h2d_point(b, batch, k, steps, spl):
     sec, reps = b.timed(tr, n, max(steps // 10, spl), stepper)
     out = {"ms_per_step": round(1e3 * sec / n, 5), "steps_per_sec": round(n / sec, 2), "repeats": len(reps),
            "bytes_per_step": flat * (256 + 4) * 4, "steps_per_upload": spl,
-           "how": "pinned host -> staging buffer on a copy stream during the previous graph launch, "
-                  "staging -> input slots on the launch stream (GanTrainer.step_many_from_host)"}
+           "how": "two alternating sets of input slots, each with its own captured graph: the copy stream uploads the "
+                  "next launch's batches from pinned host memory into the idle set while the other set's graph runs "
+                  "(GanTrainer.step_many_from_host)"}
     del tr
     torch.cuda.empty_cache()
     return out
