@@ -150,7 +150,13 @@ int ndp_adam_step(float *params, const float *grad, float *exp_avg, float *exp_a
  *
  *   phase A  ndp_step_d_grads : [first call of the step: G forward]
  *            D(real), D(fake) forward, BCE, D backward  -> D gradient
- *            (train_gan.py:165-183); with fuse_adam the D Adam update too (184)
+ *            (train_gan.py:165-183); with fuse_adam the D Adam update too (184).
+ *            `actions` / `codes` hold ONE row per FLAT row; the reference feeds D
+ *            K = num_sample identical copies of each (repeat_interleave,
+ *            train_gan.py:140-156), so on the first call of a step the real pass
+ *            runs on the FLAT distinct rows with every row's BCE term and loss
+ *            gradient weighted K: the same sums, 1/K of the rows.  Repeat calls
+ *            (run_g_forward = 0) run both passes on all M rows.
  *   phase B  ndp_step_g_grads : D(fake) forward with the UPDATED D, G loss,
  *            NDiv loss + gradient, backward through D and G -> G gradient
  *            (train_gan.py:187-202); with fuse_adam the G Adam update too (203)
