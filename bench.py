@@ -235,6 +235,9 @@ class Bench:
         while spl > 1 and n - done >= spl:
             many()                     # spl iterations, one graph replay
             done += spl
+        if stepper is None and spl > 1 and n - done > 1 and tr.use_graph and tr.reduce_fn is None:
+            tr.step_many(count=n - done)   # the remainder as one replay too (a 20-step run = 16 + 4)
+            done = n
         for _ in range(n - done):
             tr.step()                  # device noise, resident inputs
 

@@ -279,20 +279,23 @@ class GanTrainer:
             self.p2p.poll()          # a timed-out wait of an EARLIER launch aborts here (no synchronisation)
 
     @_on_own_device
-    def step_many(self, codes=None, actions=None, noise=None):
+    def step_many(self, codes=None, actions=None, noise=None, count=None):
         """`steps_per_launch` consecutive iterations in ONE graph replay.  codes [n,flat,256],
         actions [n,flat,4], noise [n,flat,K,nz] (n = steps_per_launch); None keeps what the slots
-        hold (codes/actions) or draws device noise.  With a collective between the phases
+        hold (codes/actions) or draws device noise.  `count` < steps_per_launch: only the first
+        `count` slots (a graph of its own per count).  With a collective between the phases
         (data parallel) or without graphs this is a plain loop over the slots."""
         self._check_bindings()
-        n = self.nslots
+        n = self.nslots if count is None else int(count)
+        if not 1 <= n <= self.nslots:
+            raise ValueError("count=%r outside 1..%d" % (count, self.nslots))
         if codes is not None:
-            self.codes_slots.copy_(codes.reshape(n, self.flat, CODE_DIM), non_blocking=True)
+            self.codes_slots[:n].copy_(codes.reshape(n, self.flat, CODE_DIM), non_blocking=True)
         if actions is not None:
-            self.actions_slots.copy_(actions.reshape(n, self.flat, ACTION_DIM), non_blocking=True)
+            self.actions_slots[:n].copy_(actions.reshape(n, self.flat, ACTION_DIM), non_blocking=True)
         device_noise = noise is None
         if not device_noise:
-            self.noise_slots.copy_(noise.reshape(n, self.flat, self.k, self.noise_dim), non_blocking=True)
+            self.noise_slots[:n].copy_(noise.reshape(n, self.flat, self.k, self.noise_dim), non_blocking=True)
         if self.use_graph and self.reduce_fn is None:
             self._replay(device_noise, n)
             return
