@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NDP_VERSION 120          /* 0.2.0: ndp_p2p_diagnostics / _status_async, ndp_device_pci_bus_id */
+#define NDP_VERSION 130          /* 0.3.0: ndp_fm_* (forward / next-frame model) */
 
 #define NDP_OK            0
 #define NDP_E_ARG         1      /* bad argument (shape, alignment, null) */
@@ -306,6 +306,52 @@ int64_t ndp_encoder_param_floats(void);
 int64_t ndp_encoder_workspace_floats(int64_t n_images);
 int ndp_encoder_forward(const float *packed_params, const float *images, int64_t n_images,
                         float *codes, float *workspace, void *stream);
+
+/* ------------------------------------------- forward (next-frame) model ---
+ * models.forward_encoder.ForwardAutoencoder (forward_encoder.py:20-114) and one iteration
+ * of its training loop (train_forward_model.py:98-112): U-Net of stride-2 convolutions /
+ * transposed convolutions with BatchNorm, conditioned on the 4-d action.
+ *   ndp_fm_forward      replaces  forward_autoencoder(state_cur, action)   (forward_encoder.py:105-114)
+ *                       training != 0: batch-statistics BatchNorm, returns the residual, moves the running
+ *                       statistics when running_stats != NULL; training == 0: running statistics,
+ *                       returns state_cur + residual (what control_evaluation.py / mpc_eval.py call)
+ *   ndp_fm_train_grads  replaces  loss = mse(model(cur, a), fut - cur); zero_grad(); loss.backward()
+ *                       (train_forward_model.py:102-109): loss[0] = the MSE, *loss_sum += it (NULL: not kept),
+ *                       grad = every gradient, resid_out (NULL or [n,3,128,128]) = the prediction
+ *   ndp_fm_apply_adam   replaces  optimizer.step() (:110) for the flat parameter vector, and rebuilds the
+ *                       second weight order in the workspace (step_count: the Adam state word of ndp_adam_step)
+ * Images [n,3,128,128] NCHW and actions [n,4] as the reference's loader delivers them.
+ * Parameters are ONE flat fp32 vector (ndp_fm_param_floats() floats), gradients and Adam moments have the same
+ * layout: per layer (conv1..6, deconv1..6, conv_refine_1, conv_refine_2) the weight then the bias, then per
+ * BatchNorm in use (conv1..3_bn, deconv1..6_bn, conv_refine_1_bn) weight then bias.  Weights are stored
+ * tap-major with the channel the kernels read along innermost, zero-padded:
+ *   Conv2d           [cout_pad][kh][kw][cin_pad]   = weight.permute(0, 2, 3, 1)
+ *   ConvTranspose2d  [cin_pad][kh][kw][cout_pad]   = weight.permute(0, 2, 3, 1)
+ * ndp_fm_layout(what, index, &offset, dims) describes every tensor: what 0 weight / 1 bias of layer `index`
+ * (dims = rows, taps, columns, kind 0 conv / 1 transposed, cin, cout), 2 / 3 BatchNorm weight / bias, 4 / 5
+ * running mean / variance (offsets into the running_stats vector of ndp_fm_stat_floats() floats; dims[0] =
+ * channels, dims[3] = the layer the BatchNorm follows).  Padded entries must be zero and stay zero under Adam.
+ * The reference's conv4_bn / conv5_bn are never applied (forward_encoder.py:51-54) and are not part of the vector.
+ * workspace: ndp_fm_workspace_floats(n) floats; its head holds the second weight order, which
+ * ndp_fm_pack_params (after the parameters were written from outside) and ndp_fm_apply_adam rebuild -- the
+ * same workspace pointer must be used for all calls.  ndp_fm_workspace_offset(n, t): where intermediate map t
+ * (order of FmTensor in csrc/ndp_forward_model.inc) lives, for tests. */
+int64_t ndp_fm_param_floats(void);
+int64_t ndp_fm_stat_floats(void);
+int64_t ndp_fm_workspace_floats(int64_t n_images);
+int64_t ndp_fm_workspace_offset(int64_t n_images, int tensor);
+int ndp_fm_layout(int what, int index, int64_t *offset, int64_t *dims /* [6] */);
+int ndp_fm_pack_params(const float *params, float *workspace, void *stream);
+int ndp_fm_forward(const float *params, float *running_stats, const float *state_cur,
+                   const float *actions, int64_t n_images, int training, float *out,
+                   float *workspace, void *stream);
+int ndp_fm_train_grads(const float *params, float *running_stats, const float *state_cur,
+                       const float *state_fut, const float *actions, int64_t n_images,
+                       float *grad, float *loss, float *loss_sum, float *resid_out,
+                       float *workspace, void *stream);
+int ndp_fm_apply_adam(float *params, const float *grad, float *exp_avg, float *exp_avg_sq,
+                      int32_t *step_count, float lr, float beta1, float beta2, float eps,
+                      float *workspace, void *stream);
 
 /* ------------------------------------------------------------ measurement ---
  * Per-kernel timing for bench.py: while enabled (per host thread) every kernel

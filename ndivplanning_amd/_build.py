@@ -13,7 +13,7 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 # NDP_LIB_PATH: load another build of the library (diagnostic builds with -DNDP_STAMPS / -DNDP_EXP_*; scripts/probe)
 LIB_PATH = os.environ.get("NDP_LIB_PATH") or os.path.join(LIB_DIR, "libndp_hip.so")
 SOURCES = ["ndp_kernels.hip"]
-DEPS = ["ndp_kernels.hip", "ndp_device.h", "ndp_capi.inc", "ndp_encoder.inc", os.path.join("..", "..", "include", "ndp.h")]
+DEPS = ["ndp_kernels.hip", "ndp_device.h", "ndp_capi.inc", "ndp_encoder.inc", "ndp_forward_model.inc", os.path.join("..", "..", "include", "ndp.h")]
 
 
 def _hipcc():

@@ -17,7 +17,7 @@ ACTION_DIM = 4
 MAX_NOISE_DIM = 16
 MAX_SAMPLES = 256
 ROW_PAD = 32
-EXPECTED_VERSION = 120          # NDP_VERSION of include/ndp.h this binding was written against
+EXPECTED_VERSION = 130          # NDP_VERSION of include/ndp.h this binding was written against
 
 _lib = None
 
@@ -99,6 +99,17 @@ SIGNATURES = {
     "ndp_encoder_param_floats": (c_int64, []),
     "ndp_encoder_workspace_floats": (c_int64, [c_int64]),
     "ndp_encoder_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "ndp_fm_param_floats": (c_int64, []),
+    "ndp_fm_stat_floats": (c_int64, []),
+    "ndp_fm_workspace_floats": (c_int64, [c_int64]),
+    "ndp_fm_workspace_offset": (c_int64, [c_int64, c_int]),
+    "ndp_fm_layout": (c_int, [c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
+    "ndp_fm_pack_params": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "ndp_fm_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "ndp_fm_train_grads": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p]),
+    "ndp_fm_apply_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
+                                  c_void_p, c_void_p]),
     "ndp_timing_enable": (c_int, [c_int]),
     "ndp_timing_collect": (c_int, [ctypes.c_char_p, c_int, POINTER(c_float), POINTER(c_int32), c_int]),
 }

@@ -1564,3 +1564,4 @@ __global__ __launch_bounds__(kThreads) void k_philox(float* out, int64_t n, uint
 
 #include "ndp_capi.inc"
 #include "ndp_encoder.inc"
+#include "ndp_forward_model.inc"

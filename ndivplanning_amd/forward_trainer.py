@@ -1,0 +1,91 @@
+"""One iteration of the reference's forward-model training loop (train_forward_model.py:98-112) as gfx950 kernels:
+
+    state_fut_resid_hat = forward_autoencoder(state_cur, action)      ->  ndp_fm_train_grads   (forward, training-mode
+    loss = mse(state_fut_resid_hat, state_fut - state_cur)                BatchNorm, MSE, backward: every gradient)
+    optimizer.zero_grad(); loss.backward()
+    optimizer.step()                                                   ->  ndp_fm_apply_adam
+
+The trainer owns the flat parameter vector the kernels read (include/ndp.h: forward model), its gradient, Adam moments
+and the running BatchNorm statistics; `sync_to_module()` writes them back into the `ForwardAutoencoder` (the reference
+saves the whole module: train_forward_model.py:157-163).  `reduce_fn(grad)` -- when given, called between the two
+library calls -- is where a data-parallel driver all-reduces the gradient ("same DP recipe";
+the loss is a mean over the local batch, so the driver averages)."""
+import torch
+
+from . import _capi
+from .models import forward_encoder as FE
+
+
+class ForwardModelTrainer:
+    def __init__(self, model: FE.ForwardAutoencoder, batch: int, lr: float = 2e-4, betas=(0.5, 0.999), eps: float = 1e-8,
+                 reduce_fn=None, keep_residual: bool = False):
+        self.lib = _capi.load()
+        self.model = model
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise _capi.NdpError("ForwardModelTrainer needs the model on a ROCm GPU (got %s); there is no CPU path" % dev)
+        self.device, self.batch = dev, int(batch)
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.reduce_fn = reduce_fn
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.params, self.stats = FE.pack_module(model, dev)
+        self.grad = torch.zeros_like(self.params)
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.params), torch.zeros_like(self.params)
+        self.step_word = torch.zeros(4, dtype=torch.int32, device=dev)      # Adam state word (include/ndp.h)
+        self.loss = torch.zeros(1, **f32)
+        self.loss_sum = torch.zeros(1, **f32)
+        self.resid = torch.zeros(self.batch, 3, 128, 128, **f32) if keep_residual else None
+        self.workspace = torch.empty(self.lib.ndp_fm_workspace_floats(self.batch), **f32)
+        self.steps = 0
+        with torch.cuda.device(dev):
+            _capi.check(self.lib.ndp_fm_pack_params(_capi.ptr(self.params), _capi.ptr(self.workspace),
+                                                    _capi.stream_ptr(dev)), "ndp_fm_pack_params")
+
+    def _check(self, t, shape, what):
+        if t.device != self.device or t.dtype != torch.float32 or tuple(t.shape) != shape or not t.is_contiguous():
+            raise _capi.NdpError("%s: expected a contiguous float32 %s tensor on %s, got %s %s on %s"
+                                 % (what, list(shape), self.device, t.dtype, list(t.shape), t.device))
+
+    def grads(self, state_cur, state_fut, actions):
+        """forward + loss + backward: fills .grad, .loss (device scalar, the reference's `loss`), adds it to .loss_sum."""
+        n = int(state_cur.shape[0])
+        if not 1 <= n <= self.batch:
+            raise _capi.NdpError("batch of %d images with a trainer built for at most %d" % (n, self.batch))
+        self._check(state_cur, (n, 3, 128, 128), "state_cur")
+        self._check(state_fut, (n, 3, 128, 128), "state_fut")
+        self._check(actions, (n, 4), "actions")
+        p = _capi.ptr
+        with torch.cuda.device(self.device):
+            _capi.check(self.lib.ndp_fm_train_grads(p(self.params), p(self.stats), p(state_cur), p(state_fut), p(actions), n,
+                                                    p(self.grad), p(self.loss), p(self.loss_sum),
+                                                    p(self.resid) if self.resid is not None else None,
+                                                    p(self.workspace), _capi.stream_ptr(self.device)), "ndp_fm_train_grads")
+        return self.loss
+
+    def apply(self):
+        """optimizer.step()"""
+        p = _capi.ptr
+        with torch.cuda.device(self.device):
+            _capi.check(self.lib.ndp_fm_apply_adam(p(self.params), p(self.grad), p(self.exp_avg), p(self.exp_avg_sq),
+                                                   p(self.step_word), self.lr, self.betas[0], self.betas[1], self.eps,
+                                                   p(self.workspace), _capi.stream_ptr(self.device)), "ndp_fm_apply_adam")
+        self.steps += 1
+
+    def step(self, state_cur, state_fut, actions):
+        """The loop body of train_forward_model.py:98-112 for one frame pair; returns the loss (device scalar)."""
+        self.grads(state_cur, state_fut, actions)
+        if self.reduce_fn is not None:
+            self.reduce_fn(self.grad)
+        self.apply()
+        return self.loss
+
+    def sync_to_module(self):
+        FE.unpack_into_module(self.model, self.params, self.stats, batches_tracked=self.steps)
+        return self.model
+
+    def named_gradients(self):
+        """name -> gradient in the module's own tensor shapes (tests, inspection)."""
+        return FE.unpack_vector(self.grad, self.model)
+
+    def named_parameters(self):
+        return FE.unpack_vector(self.params, self.model)
