@@ -188,10 +188,10 @@ def timing_enable(on):
 def timing_collect():
     """{kernel name: (total ms, launches)} since timing was enabled / last collected."""
     lib = load()
-    names = ctypes.create_string_buffer(2048)
-    ms = (c_float * 32)()
-    counts = (c_int32 * 32)()
-    n = lib.ndp_timing_collect(names, 2048, ms, counts, 32)
+    names = ctypes.create_string_buffer(4096)
+    ms = (c_float * 64)()
+    counts = (c_int32 * 64)()
+    n = lib.ndp_timing_collect(names, 4096, ms, counts, 64)
     keys = [k for k in names.value.decode().split(";") if k]
     return {keys[i]: (float(ms[i]), int(counts[i])) for i in range(min(n, len(keys)))}
 

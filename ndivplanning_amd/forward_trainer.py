@@ -79,6 +79,26 @@ class ForwardModelTrainer:
         self.apply()
         return self.loss
 
+    # intermediate maps of the last grads() call (tests, inspection): name -> (workspace tensor index, side, channels kept)
+    _MAPS = {"feat1": (1, 64, 128, 64, 128), "up5": (1, 64, 128, 0, 64), "feat2": (2, 32, 256, 128, 256), "up4": (2, 32, 256, 0, 128),
+             "feat3": (3, 16, 512, 256, 512), "up3": (3, 16, 512, 0, 256), "feat4": (4, 8, 1024, 512, 1024),
+             "up2": (4, 8, 1024, 0, 512), "feat5": (5, 4, 2048, 1024, 2048), "up1": (5, 4, 2048, 0, 1024),
+             "up6": (16, 128, 32, 0, 32), "r1": (18, 128, 32, 0, 16)}
+
+    def activation(self, name, n):
+        """Post-ReLU map `name` (feat1..5, up1..6, r1) of the last call on n images, NCHW."""
+        idx, side, ld, c0, c1 = self._MAPS[name]
+        off = self.lib.ndp_fm_workspace_offset(n, idx)
+        view = self.workspace[off:off + n * side * side * ld].view(n, side, side, ld)
+        return view[..., c0:c1].permute(0, 3, 1, 2).contiguous()
+
+    def load_from_module(self):
+        """Take parameters and running statistics from the module again (after they were changed from outside)."""
+        self.params, self.stats = FE.pack_module(self.model, self.device)
+        with torch.cuda.device(self.device):
+            _capi.check(self.lib.ndp_fm_pack_params(_capi.ptr(self.params), _capi.ptr(self.workspace),
+                                                    _capi.stream_ptr(self.device)), "ndp_fm_pack_params")
+
     def sync_to_module(self):
         FE.unpack_into_module(self.model, self.params, self.stats, batches_tracked=self.steps)
         return self.model

@@ -1,0 +1,119 @@
+"""Forward-model training script -- mirror of the reference's `train_forward_model.py` (same CLI, same YAML keys
+`training.forward.*`, same `train(config)` entry point, epoch log line and checkpoint files), with the loop body
+(train_forward_model.py:98-112) replaced by `ForwardModelTrainer.step`: forward, MSE, backward and Adam as gfx950
+kernels (csrc/ndp_forward_model.inc).
+
+What differs from the reference, on purpose:
+  * the per-step `loss.cpu()` read (train_forward_model.py:113-114) becomes one read per epoch of a sum kept on the
+    device;
+  * the StepLR scheduler the reference constructs and never steps (train_forward_model.py:86) is not constructed;
+  * visdom image panels are attempted only if visdom is importable;
+  * `train_data_path: synthetic:<N>` gives seeded synthetic trajectories (the HDF5 loader needs h5py, see
+    utils/trajectory_loader.py).
+The whole module is saved every `epochs_per_stage` epochs as the reference does (train_forward_model.py:151-163), after
+the trainer's flat vectors are written back into it."""
+import importlib
+import logging
+import os
+from argparse import ArgumentParser
+
+import numpy as np
+import torch
+from torch.utils import data
+
+from .forward_trainer import ForwardModelTrainer
+from .models.forward_encoder import Decoder, Encoder, ForwardAutoencoder
+from .train_gan import _get, denorm, make_dataset, norm  # noqa: F401
+from .utils.argparse_util import override_dotmap
+from .utils.cli_arguments.common_arguments import add_common_arguments
+from .utils.file import make_paths_absolute
+
+
+def bind_reference_class_paths():
+    """Whole-module checkpoints must record `models.forward_encoder.ForwardAutoencoder` (/ Encoder / Decoder): the
+    path the reference's evaluation scripts unpickle (control_evaluation.py:177-180).  See train_gan.py."""
+    missing = []
+    try:
+        mod = importlib.import_module("models.forward_encoder")
+    except ImportError:
+        mod = None
+    for cls in (ForwardAutoencoder, Encoder, Decoder):
+        if mod is not None and getattr(mod, cls.__name__, None) is cls:
+            cls.__module__ = "models.forward_encoder"
+        else:
+            missing.append("models.forward_encoder.%s" % cls.__name__)
+    if missing:
+        logging.warning("checkpoints will record ndivplanning_amd.* class paths: %s do(es) not resolve to this "
+                        "implementation (is the repository root, with its models/ shims, on sys.path?)", ", ".join(missing))
+    return missing
+
+
+def train(config):
+    f = config.training.forward
+    random_seed = int(config.random_seed)
+    lr_rate, num_epochs, batch_size = float(f.learning_rate), int(f.num_epochs), int(f.batch_size)
+    epochs_per_stage = int(f.epochs_per_stage)
+    device = torch.device(config.gpu_id if torch.cuda.is_available() else "cpu")
+    if device.type != "cuda":
+        from . import _capi
+        raise _capi.NdpError("train_forward_model needs a ROCm GPU (gpu_id %r resolves to %s); there is no CPU path"
+                             % (config.gpu_id, device))
+    bind_reference_class_paths()
+    torch.manual_seed(random_seed)                                   # train_forward_model.py:60-61
+    np.random.seed(random_seed)
+    display = None
+    try:
+        from .vis_tools import visualizer                            # optional (visdom)
+        display = visualizer(port=config.log_port)
+    except Exception:                                                # pragma: no cover - depends on the image
+        display = None
+
+    dataset = make_dataset(config)
+    if getattr(dataset, "mode", "images") != "images":
+        raise ValueError("the forward model trains on images: use `synthetic:<N>:images` or an HDF5 directory")
+    loader = data.DataLoader(dataset, batch_size=batch_size, shuffle=True)
+
+    model = ForwardAutoencoder().to(device)                          # train_forward_model.py:67-70
+    model.decoder.weight_init(mean=0.0, std=0.02)
+    model.encoder.weight_init(mean=0.0, std=0.02)
+    model.train()
+    trainer = ForwardModelTrainer(model, batch=batch_size, lr=lr_rate, betas=(0.5, 0.999))
+
+    history = []
+    step = 0
+    for epoch in range(num_epochs):
+        trainer.loss_sum.zero_()
+        pairs = 0
+        for images, _, actions, _ in loader:
+            images = images.to(device, non_blocking=True).float()
+            actions = actions.to(device, non_blocking=True).float()
+            for image_num in range(dataset.seq_length - 1):          # train_forward_model.py:98-112
+                trainer.step(images[:, image_num].contiguous(), images[:, image_num + 1].contiguous(),
+                             actions[:, image_num].contiguous())
+                step += 1
+                pairs += 1
+        avg_loss = float(trainer.loss_sum.item()) / max(pairs, 1)    # (seq_length - 1) * len(loader) terms
+        history.append(avg_loss)
+        if display is not None:                                      # pragma: no cover
+            display.plot("loss", "train", "Forward Model Loss", epoch, avg_loss)
+        logging.info("{}, {}: reconstruction loss per epoch: {}".format(epoch, step, avg_loss))
+        if epoch % epochs_per_stage == epochs_per_stage - 1:          # train_forward_model.py:151-163
+            os.makedirs(config.forward_save_path, exist_ok=True)
+            trainer.sync_to_module()
+            torch.cuda.synchronize(device)
+            torch.save(model, os.path.join(config.forward_save_path, "forward_autoencoder_{}.pt".format(str(epoch))))
+    trainer.sync_to_module()
+    return history
+
+
+def main(argv=None):
+    parser = ArgumentParser(description="Interact with your training script")
+    parser = add_common_arguments(parser)
+    args = parser.parse_args(argv)
+    config = override_dotmap(args, "config_file")
+    config = make_paths_absolute(os.getcwd(), config, log_not_exist=True)
+    return train(config)
+
+
+if __name__ == "__main__":
+    main()

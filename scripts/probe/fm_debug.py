@@ -16,10 +16,10 @@ from oracle import forward_model_oracle as FO
 torch.set_num_threads(8)
 n = int(os.environ.get("N", 2))
 dev = "cuda:0"
-state = FO.init_forward_model_state(5)
+state = FO.init_forward_model_state(int(os.environ.get("SEED", 5)))
 model = FE.ForwardAutoencoder()
 model.load_state_dict({k: v for k, v in state.items()}, strict=False)
-gen = torch.Generator().manual_seed(6)
+gen = torch.Generator().manual_seed(int(os.environ.get("DATA_SEED", 6)))
 frames = torch.rand(n, 3, 3, 128, 128, generator=gen) * 2.0 - 1.0
 actions = torch.rand(n, 3, 4, generator=gen) * 2.0 - 1.0
 cur, fut, act = frames[:, 0].contiguous(), frames[:, 1].contiguous(), actions[:, 0].contiguous()
@@ -104,3 +104,17 @@ for name, p in ref.named_parameters():
     if p.grad is None:
         continue
     report(name, mine[name].cpu().double(), p.grad)
+
+# where the error of one tensor sits (FOCUS=<parameter name>): per slice along each of the first two dimensions
+focus = os.environ.get("FOCUS")
+if focus:
+    g = dict(ref.named_parameters())[focus].grad
+    e = (mine[focus].cpu().double() - g)
+    print("focus", focus, "rel L2", (e.norm() / g.norm()).item())
+    for dim in (0, 1):
+        other = [d for d in range(e.dim()) if d != dim]
+        en = (e * e).sum(dim=other).sqrt()
+        gn = (g * g).sum(dim=other).sqrt()
+        top = torch.topk(en, 5)
+        print("  dim %d: top error slices" % dim, [(int(i), "%.2e" % v, "rel %.2e" % (v / gn[i])) for v, i in zip(top.values, top.indices)],
+              "median slice error %.2e" % en.median().item())

@@ -1,0 +1,285 @@
+"""GPU parity of the forward (next-frame) model kernels (csrc/ndp_forward_model.inc) with
+the oracle's restatement of models/forward_encoder.py + train_forward_model.py:98-112 and with the golden vector the
+REFERENCE's own ForwardAutoencoder / MSELoss / Adam produced (tests/golden/forward_model_case.npz)."""
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import forward_model_oracle as FO
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+LR = 2e-4
+
+# Biases of the layers a BatchNorm follows: the batch mean is subtracted right after them, so their gradient is zero
+# but for rounding (1e-9 of the weight gradient's scale here, 1e-17 in an fp64 reference) and Adam turns that noise
+# into steps of up to lr whose sign no two implementations share.  They have no effect on the function.
+NOISE_BIASES = tuple("%s.bias" % n for n in ("encoder.conv1", "encoder.conv2", "encoder.conv3", "decoder.deconv1",
+                                             "decoder.deconv2", "decoder.deconv3", "decoder.deconv4", "decoder.deconv5",
+                                             "decoder.deconv6", "decoder.conv_refine_1"))
+
+
+def _inputs(data_seed, n):
+    gen = torch.Generator().manual_seed(data_seed)
+    frames = torch.rand(n, 3, 3, 128, 128, generator=gen) * 2.0 - 1.0
+    actions = torch.rand(n, 3, 4, generator=gen) * 2.0 - 1.0
+    return frames, actions
+
+
+def _sums(t):
+    t = t.detach().double().cpu()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()])
+
+
+def _hip_trainer(seed, n, **kw):
+    from ndivplanning_amd.forward_trainer import ForwardModelTrainer
+    from ndivplanning_amd.models import forward_encoder as FE
+    state = FO.init_forward_model_state(seed)
+    model = FE.ForwardAutoencoder()
+    model.load_state_dict(state)
+    model = model.to(DEV).train()
+    return ForwardModelTrainer(model, batch=n, lr=LR, **kw), state
+
+
+def test_two_training_iterations_match_the_reference_golden():
+    g = load_golden("forward_model_case")
+    seed, data_seed, n = (int(v) for v in g["meta"])
+    tr, _ = _hip_trainer(seed, n, keep_residual=True)
+    frames, actions = _inputs(data_seed, n)
+    names = [str(s) for s in g["names"]]
+    for it in range(2):
+        cur, fut, act = (t.contiguous().to(DEV) for t in (frames[:, it], frames[:, it + 1], actions[:, it]))
+        tr.grads(cur, fut, act)
+        assert abs(tr.loss.item() - float(g["s%d.loss" % it])) <= 2e-6
+        resid = tr.resid.cpu()
+        np.testing.assert_allclose(resid[:, :, ::16, ::16].numpy(), g["s%d.resid_sample" % it], atol=2e-5)
+        np.testing.assert_allclose(_sums(resid), g["s%d.resid_sums" % it], rtol=1e-4)
+        grads = tr.named_gradients()
+        tr.apply()
+        params = tr.named_parameters()
+        for i, name in enumerate(names):
+            want = g["s%d.grad_sums" % it][i]
+            if name not in grads:                         # conv4_bn / conv5_bn: constructed, never applied
+                assert not want.any(), name
+                continue
+            if name in NOISE_BIASES:
+                wscale = g["s%d.grad_sums" % it][names.index(name[:-4] + "weight")][1]
+                assert _sums(grads[name])[1] <= 1e-5 * wscale, name
+                continue
+            assert abs(_sums(grads[name])[1] - want[1]) <= 5e-4 * max(want[1], 1e-12), (name, it)
+            wantp = g["s%d.param_sums" % it][i]
+            assert abs(_sums(params[name])[1] - wantp[1]) <= 2e-5 * max(wantp[1], 1e-12) + 1e-7, (name, it)
+    model = tr.sync_to_module()
+    sd = model.state_dict()
+    keys = [k for k in sd if "running_" in k]
+    for k, want in zip(keys, g["running_sums"]):
+        got = _sums(sd[k])
+        if k.endswith("running_var"):
+            np.testing.assert_allclose(got, want, rtol=1e-4, err_msg=k)
+        else:
+            # batch means of zero-mean maps are ~1e-3 of the maps' scale: their rounding error is relative to THAT scale
+            # (the signed sum cancels further and is not compared)
+            np.testing.assert_allclose(got[1:], want[1:], rtol=5e-3, atol=1e-9, err_msg=k)
+    assert int(sd["decoder.deconv3_bn.num_batches_tracked"]) == 2
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("n", [1, 3, 8])
+def test_training_iterations_against_the_oracle_elementwise(n):
+    """Every gradient of two iterations against the oracle, adjudicated by the oracle's own arithmetic in fp64: the error of
+    the kernels against fp64 may be at most twice the fp32 oracle's (or 2e-5).  Two things keep the comparison tight:
+      * the ReLU decisions of the run under test are injected into both oracles (FO.forward, relu_masks): among 10^6
+        pre-activations some are within rounding of zero, and ONE element decided the other way moves a small map's
+        gradients by 1e-3 -- measured: seed 14, n = 3, an element of up5 -- while the activations themselves agree to 1e-6;
+      * iteration 2 starts from the fp32 oracle's parameters (Adam turns rounding-level gradients into steps of lr whose
+        sign implementations do not share, so the parameters after a step are compared by their distribution instead)."""
+    torch.set_num_threads(8)
+    tr, state = _hip_trainer(11 + n, n, keep_residual=True)
+    state64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in state.items()}
+    oracle = FO.ForwardModelTrainer(state, lr=LR)
+    frames, actions = _inputs(20 + n, n)
+    for it in range(2):
+        cur, fut, act = frames[:, it].contiguous(), frames[:, it + 1].contiguous(), actions[:, it].contiguous()
+        if it == 1:                                            # teacher forcing: the oracle's parameters and statistics
+            with torch.no_grad():
+                tr.model.load_state_dict({k: v.detach() for k, v in state.items()})
+            tr.load_from_module()
+            state64 = {k: (v.detach().double() if v.is_floating_point() else v.clone()) for k, v in state.items()}
+        tr.grads(cur.to(DEV), fut.to(DEV), act.to(DEV))
+        masks = {site: (tr.activation(site, n) > 0).cpu() for site in FO.RELU_SITES}
+        want = oracle.step(cur, fut, act, relu_masks=masks)
+        exact = FO.ForwardModelTrainer(state64, lr=LR).step(cur.double(), fut.double(), act.double(), relu_masks=masks)
+        assert abs(tr.loss.item() - exact["loss"].item()) <= 1e-5 * max(1.0, exact["loss"].item())
+        assert float((tr.resid.cpu().double() - exact["resid"]).abs().max()) <= 2e-5
+        grads = tr.named_gradients()
+        for name, ref in want["grads"].items():
+            if ref is None:
+                assert name not in grads
+                continue
+            mine = grads[name].cpu()
+            if name in NOISE_BIASES:
+                wscale = float(want["grads"][name[:-4] + "weight"].abs().max())
+                assert float(mine.abs().max()) <= 1e-4 * wscale, name
+                continue
+            err_mine, err_ref = _rel(mine, exact["grads"][name]), _rel(ref, exact["grads"][name])
+            assert err_mine <= max(2e-5, 2.0 * err_ref), (name, n, it, err_mine, err_ref)
+        tr.apply()
+        params = tr.named_parameters()
+        for name in want["grads"]:
+            if name in NOISE_BIASES or name not in params:
+                continue
+            diff = (params[name].cpu() - state[name].detach()).abs()
+            assert float(diff.max()) <= 2.2 * LR, name              # one Adam step moves an element by at most ~lr
+            assert float(diff.mean()) <= 0.03 * LR, (name, float(diff.mean()))
+    assert float(tr.loss_sum.item()) > 0.0
+
+
+def test_relu_decisions_differ_from_the_oracle_only_at_rounding_level_preactivations():
+    """What the mask injection above leaves unchecked: the decisions themselves.  Against the fp64 oracle they may differ only
+    where the pre-activation is within rounding of zero, and only in a handful of the ~10^7 elements."""
+    n = 2
+    tr, state = _hip_trainer(31, n)
+    frames, actions = _inputs(32, n)
+    cur, fut, act = frames[:, 0].contiguous(), frames[:, 1].contiguous(), actions[:, 0].contiguous()
+    tr.grads(cur.to(DEV), fut.to(DEV), act.to(DEV))
+    state64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in state.items()}
+    recorded = {}                                              # the fp64 oracle's pre-activations, site by site
+    import torch.nn.functional as F
+    real_relu = F.relu
+    sites = iter(FO.RELU_SITES)
+
+    def spy(x, *a, **kw):
+        recorded[next(sites)] = x.detach().clone()
+        return real_relu(x, *a, **kw)
+    FO.F.relu = spy
+    try:
+        with torch.no_grad():
+            FO.forward(state64, cur.double(), act.double(), training=True)
+    finally:
+        FO.F.relu = real_relu
+    assert sorted(recorded) == sorted(FO.RELU_SITES)
+    total = flips = 0
+    for site, pre in recorded.items():
+        mine = tr.activation(site, n).cpu().double()
+        differ = (mine > 0) != (pre > 0)
+        total += pre.numel()
+        flips += int(differ.sum())
+        assert float(pre[differ].abs().max() if differ.any() else 0.0) <= 3e-5, site   # only rounding-level pre-activations
+        assert float((mine - pre.clamp_min(0)).abs().max()) <= 3e-5, site
+    assert flips <= 20 and total > 3_000_000, (flips, total)
+
+
+def test_eval_and_no_grad_forward_of_the_module_match_the_oracle():
+    from ndivplanning_amd.models import forward_encoder as FE
+    n = 2
+    tr, state = _hip_trainer(3, n)
+    oracle = FO.ForwardModelTrainer(state, lr=LR)
+    frames, actions = _inputs(4, n)
+    cur, fut, act = frames[:, 0].contiguous(), frames[:, 1].contiguous(), actions[:, 0].contiguous()
+    oracle.step(cur, fut, act)
+    tr.step(cur.to(DEV), fut.to(DEV), act.to(DEV))
+    model = tr.sync_to_module()
+    # eval mode, grad mode on, parameters requiring grad: how control_evaluation.py / mpc_eval.py call it
+    model.eval()
+    pred = model(frames[:, 2].to(DEV), actions[:, 2].to(DEV))
+    with torch.no_grad():
+        want = FO.forward(state, frames[:, 2], actions[:, 2], training=False)
+    assert pred.shape == (n, 3, 128, 128) and not pred.requires_grad
+    assert float((pred.cpu() - want).abs().max()) <= 2e-4
+    # training mode under no_grad: the residual, and the running statistics move
+    model.train()
+    before = model.decoder.deconv2_bn.running_mean.clone()
+    with torch.no_grad():
+        resid = model(frames[:, 2].to(DEV), actions[:, 2].to(DEV))
+        want = FO.forward(state, frames[:, 2], actions[:, 2], training=True)
+    assert float((resid.cpu() - want).abs().max()) <= 2e-4
+    assert not torch.equal(before, model.decoder.deconv2_bn.running_mean)
+    np.testing.assert_allclose(model.decoder.deconv2_bn.running_mean.cpu().numpy(),
+                               state["decoder.deconv2_bn.running_mean"].numpy(), rtol=1e-3, atol=1e-6)
+    assert int(model.decoder.deconv2_bn.num_batches_tracked) == int(state["decoder.deconv2_bn.num_batches_tracked"])
+    # a CPU tensor has no path
+    from ndivplanning_amd import _capi
+    with pytest.raises(_capi.NdpError), torch.no_grad():
+        model(frames[:, 2], actions[:, 2].to(DEV))
+    # the reference saves the whole module (train_forward_model.py:157-163)
+    buf = io.BytesIO()
+    torch.save(model, buf)
+    buf.seek(0)
+    again = torch.load(buf, weights_only=False)                  # our own file
+    assert isinstance(again, FE.ForwardAutoencoder)
+    assert torch.equal(again.encoder.conv3.weight.cpu(), model.encoder.conv3.weight.cpu())
+
+
+def test_a_step_is_bit_reproducible_and_smaller_batches_reuse_the_trainer():
+    tr1, _ = _hip_trainer(9, 4)
+    tr2, _ = _hip_trainer(9, 4)
+    frames, actions = _inputs(10, 4)
+    for tr in (tr1, tr2):
+        for it in range(2):
+            tr.step(frames[:, it].contiguous().to(DEV), frames[:, it + 1].contiguous().to(DEV), actions[:, it].contiguous().to(DEV))
+    assert torch.equal(tr1.params, tr2.params) and torch.equal(tr1.grad, tr2.grad) and torch.equal(tr1.stats, tr2.stats)
+    # a ragged final batch (the reference's loader has no drop_last): 3 images through the 4-image trainer
+    loss = tr1.step(frames[:3, 0].contiguous().to(DEV), frames[:3, 1].contiguous().to(DEV), actions[:3, 0].contiguous().to(DEV))
+    assert torch.isfinite(loss).all() and torch.isfinite(tr1.params).all()
+    from ndivplanning_amd import _capi
+    with pytest.raises(_capi.NdpError):
+        tr1.grads(torch.zeros(5, 3, 128, 128, device=DEV), torch.zeros(5, 3, 128, 128, device=DEV), torch.zeros(5, 4, device=DEV))
+
+
+def test_train_script_epoch_matches_an_oracle_replay(tmp_path):
+    """ndivplanning_amd/train_forward_model.py::train (mirror of the reference's script) on synthetic trajectories against
+    a CPU replay with the oracle: same seeding order (seed -> model construction -> weight_init -> loader shuffle)."""
+    import models.forward_encoder as shim
+    from ndivplanning_amd.train_forward_model import train
+    from ndivplanning_amd.train_gan import make_dataset
+    from ndivplanning_amd.utils.file import AttrDict
+    torch.set_num_threads(8)
+
+    def config():
+        return AttrDict({"random_seed": 0, "train_data_path": "synthetic:3:images", "gpu_id": 0, "trajectory_length": 3,
+                         "forward_save_path": str(tmp_path / "fm"),
+                         "training": {"forward": {"num_epochs": 1, "learning_rate": LR, "report_feq": 10, "batch_size": 2,
+                                                  "epochs_per_stage": 1, "step_lr_gamma": 0.1}}})
+    # the reference initialises the weights ON the device (train_forward_model.py:67-70: .to(gpu_id), then weight_init):
+    # they come from the device's generator, so the replay takes the initial state from the run itself
+    from ndivplanning_amd import train_forward_model as script
+    initial = {}
+    real_trainer = script.ForwardModelTrainer
+
+    def spy(model, **kw):
+        initial.update({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+        return real_trainer(model, **kw)
+    script.ForwardModelTrainer = spy
+    try:
+        hist = train(config())
+    finally:
+        script.ForwardModelTrainer = real_trainer
+    cfg = config()
+    torch.manual_seed(cfg.random_seed)
+    np.random.seed(cfg.random_seed)
+    from ndivplanning_amd.models import forward_encoder as FE
+    FE.ForwardAutoencoder()                                     # consumes the CPU stream as the run's construction did
+    state = initial
+    ds = make_dataset(cfg)
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=True)
+    oracle = FO.ForwardModelTrainer(state, lr=LR)
+    total, count = 0.0, 0
+    for images, _, actions, _ in loader:
+        for i in range(ds.seq_length - 1):
+            total += oracle.step(images[:, i].contiguous(), images[:, i + 1].contiguous(), actions[:, i].contiguous())["loss"].item()
+            count += 1
+    assert count == 4 and len(hist) == 1                      # batches of 2 and 1 trajectories x 2 frame pairs
+    assert abs(hist[0] - total / count) <= 2e-5
+    saved = torch.load(str(tmp_path / "fm" / "forward_autoencoder_0.pt"), weights_only=False)   # our own file
+    assert isinstance(saved, shim.ForwardAutoencoder) and type(saved).__module__ == "models.forward_encoder"
+    for name in ("decoder.deconv2.weight", "encoder.conv5.weight", "decoder.deconv4_bn.weight"):
+        diff = (saved.state_dict()[name].cpu() - state[name].detach()).abs()
+        assert float(diff.mean()) <= 0.05 * LR, (name, float(diff.mean()))
+    np.testing.assert_allclose(saved.state_dict()["decoder.deconv5_bn.running_var"].cpu().numpy(),
+                               state["decoder.deconv5_bn.running_var"].numpy(), rtol=1e-3)
