@@ -321,10 +321,13 @@ class GanTrainer:
             self._stage = {"stream": torch.cuda.Stream(self.device), "next": 0,
                            "uploaded": [torch.cuda.Event(), torch.cuda.Event()],
                            "read": [torch.cuda.Event(), torch.cuda.Event()]}
+            # the second slot set is allocated (and zero-filled) on the launch stream: the copy stream must not
+            # upload into it before that fill has run (it would be overwritten with zeros when the fill ran later)
+            self._inputs(0, 1)
+            self._stage["stream"].wait_stream(torch.cuda.current_stream(self.device))
         st = self._stage
         sset = st["next"]
         st["next"] = 1 - sset
-        self._inputs(0, sset)                             # allocates the second set on first use
         codes = self.codes_slots if sset == 0 else self._alt_slots[0]
         actions = self.actions_slots if sset == 0 else self._alt_slots[1]
         main = torch.cuda.current_stream(self.device)

@@ -98,6 +98,12 @@ for wsn, mod, c in (("RAWR1", "decoder.conv_refine_1", 16), ("RAWU6", "decoder.d
                     ("RAW1", "encoder.conv1", 64)):
     report("d " + mod, ws(wsn)[:, :c], inter[mod].grad)
 report("d code", ws("DZ")[:, :128], inter["encoder.conv6"].grad.reshape(n, 128))
+print("---- d (post-ReLU map) * mask, from the d-cat buffers, against the gradient at the BatchNorm output")
+for cat, dcat, lo, hi, mod in (("CAT4", "DCAT4", 256, 512, "encoder.conv3_bn"), ("CAT5", "DCAT5", 128, 256, "encoder.conv2_bn"),
+                               ("CAT6", "DCAT6", 64, 128, "encoder.conv1_bn"), ("CAT4", "DCAT4", 0, 256, "decoder.deconv3_bn"),
+                               ("CAT3", "DCAT3", 0, 512, "decoder.deconv2_bn")):
+    y, dy = ws(cat)[:, lo:hi], ws(dcat)[:, lo:hi]
+    report("%s[%d:%d] * mask" % (dcat, lo, hi), dy * (y > 0), inter[mod].grad)
 print("---- gradients")
 mine = tr.named_gradients()
 for name, p in ref.named_parameters():
