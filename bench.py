@@ -31,6 +31,8 @@ Rank 0 prints one JSON line (contract in the task statement) with extra objects:
                1,024 unique frames + the fused step at M = 5,376 (N = 1);
   large_m      the config-5 per-GPU shard (B = 128, K = 32) and B = 1,024 / K = 6: whole-step
                fraction of the fp32-MFMA peak where the matrix pipe, not launch latency, is the story;
+  forward_model    SURVEY.md section 8 row f4: one iteration of train_forward_model.py (U-Net forward, MSE,
+               backward, Adam) at batch 8 and 32, with its kernel-time shares and the oracle timed on the CPU (N = 1);
   strong_config3, config5_shard   (N > 1) global batch 256 split over the ranks, and the config-5 shard
                per rank, with the gradient exchange that ran and both exchanges timed.
 """
@@ -384,6 +386,100 @@ def config4_point(b, steps):
     return out
 
 
+# forward (next-frame) model, SURVEY.md section 8 row f4: MACs per image of one forward pass, layer by layer
+# (models/forward_encoder.py:20-97): conv1..6, deconv1..6, conv_refine_1, conv_refine_2
+FM_FWD_MACS = (64 * 64 * 64 * 27 + 4 * 75_497_472 + 128 * 16384            # encoder: 311.2 M
+               + 132 * 1024 * 16 + 5 * 268_435_456                          # deconv1, deconv2..6
+               + 128 * 128 * 16 * 288 + 128 * 128 * 3 * 144)                # refinement
+FM_STEP_FLOP_PER_IMAGE = 2.0 * (3 * FM_FWD_MACS - 64 * 64 * 64 * 27)        # + data and weight gradients (conv1 has no data gradient)
+
+
+def forward_model_point(b, cpu_seconds):
+    """One iteration of train_forward_model.py:98-112 (forward, MSE, backward, Adam) at the reference's batch of 8 images
+    and at 32: ForwardModelTrainer.step on resident synthetic frames, timed with events on the launch stream; the kernel
+    table comes from the library's per-launch events (ndp_timing_*).  FLOPs are the reference's (2 x MACs of the
+    convolutions / transposed convolutions, forward + both gradients)."""
+    from ndivplanning_amd import _capi
+    from ndivplanning_amd.forward_trainer import ForwardModelTrainer
+    from ndivplanning_amd.models import forward_encoder as FE
+    out = {"workload": "train_forward_model.py:98-112, one frame pair: ForwardAutoencoder forward (training-mode BatchNorm), "
+                       "MSE, backward, Adam; synthetic 3x128x128 frames, weight_init(0, 0.02)",
+           "gflop_per_image": round(FM_STEP_FLOP_PER_IMAGE / 1e9, 3)}
+    for n, steps in ((8, 40), (32, 16)):
+        torch.manual_seed(0)
+        model = FE.ForwardAutoencoder()
+        model.decoder.weight_init(0.0, 0.02)
+        model.encoder.weight_init(0.0, 0.02)
+        tr = ForwardModelTrainer(model.to(b.dev).train(), batch=n)
+        gen = torch.Generator().manual_seed(1)
+        cur, fut = ((torch.rand(n, 3, 128, 128, generator=gen) * 2 - 1).to(b.dev) for _ in range(2))
+        act = (torch.rand(n, 4, generator=gen) * 2 - 1).to(b.dev)
+        for _ in range(3):
+            tr.step(cur, fut, act)
+        torch.cuda.synchronize(b.dev)
+        reps = []
+        for _ in range(5):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev[0].record()
+            for _ in range(steps):
+                tr.step(cur, fut, act)
+            ev[1].record()
+            torch.cuda.synchronize(b.dev)
+            reps.append(ev[0].elapsed_time(ev[1]) / steps)
+        ms = statistics.median(reps)
+        _capi.timing_enable(True)
+        for _ in range(3):
+            tr.step(cur, fut, act)
+        torch.cuda.synchronize(b.dev)
+        timed = _capi.timing_collect()
+        _capi.timing_enable(False)
+        groups = {}
+        for name, (tot, cnt) in timed.items():
+            key = name.split("[")[0]
+            g = groups.setdefault(key, [0.0, 0])
+            g[0] += tot
+            g[1] += cnt
+        total = sum(v[0] for v in groups.values())
+        tflops = FM_STEP_FLOP_PER_IMAGE * n / (ms * 1e-3) / 1e12
+        heavy = {nm: v for nm, v in timed.items() if nm.startswith(("k_fm_gemm[deconv", "k_fm_dgrad[deconv", "k_fm_wgrad[deconv"))
+                 and nm[-2] in "2345"}
+        heavy_tflops = {nm: round(2.0 * 268_435_456 * n / (v[0] / v[1] * 1e-3) / 1e12, 1) for nm, v in heavy.items()}
+        point = {"batch": n, "ms_per_step": round(ms, 4), "steps_per_sec": round(1e3 / ms, 2),
+                 "images_per_sec": round(n * 1e3 / ms, 1), "tflops": round(tflops, 2),
+                 "frac_of_fp32_mfma_peak": round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
+                 "repeat_ms_per_step": [round(r, 4) for r in reps], "loss": float(tr.loss.item()),
+                 "launches_per_step": sum(v[1] for v in groups.values()) // 3,
+                 "kernel_time_share": {k_: {"us_per_step": round(v[0] / 3 * 1e3, 1), "launches_per_step": v[1] // 3,
+                                            "share": round(v[0] / total, 4)}
+                                       for k_, v in sorted(groups.items(), key=lambda kv: -kv[1][0])},
+                 "deconv2to5_tflops": {"min": min(heavy_tflops.values()), "max": max(heavy_tflops.values()),
+                                       "note": "the 12 launches of 268 M MAC per image each (deconv2..5 forward, data and "
+                                               "weight gradient), from their HIP-event durations; fp32 MFMA peak %.1f"
+                                               % MFMA_F32_PEAK_TFLOPS}}
+        out["batch%d" % n] = point
+        del tr, model
+        torch.cuda.empty_cache()
+    if cpu_seconds > 0:
+        from oracle import forward_model_oracle as FO
+        n = 8
+        state = FO.init_forward_model_state(0)
+        oracle = FO.ForwardModelTrainer(state, lr=2e-4)
+        gen = torch.Generator().manual_seed(1)
+        cur, fut = (torch.rand(n, 3, 128, 128, generator=gen) * 2 - 1 for _ in range(2))
+        act = torch.rand(n, 4, generator=gen) * 2 - 1
+        oracle.step(cur, fut, act)
+        cnt, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < cpu_seconds:
+            oracle.step(cur, fut, act)
+            cnt += 1
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(cnt / dt, 3), "unit": "steps/s", "kind": "port", "threads": torch.get_num_threads(),
+                               "sample": "%d iterations at batch 8 of the oracle's restatement (torch %s CPU fp32 conv / "
+                                         "conv_transpose / batch_norm + Adam) in %.1f s" % (cnt, torch.__version__, dt),
+                               "gpu_over_cpu": round(out["batch8"]["steps_per_sec"] / (cnt / dt), 1)}
+    return out
+
+
 def h2d_point(b, batch, k, steps, spl):
     """Config 2 with a fresh batch per step uploaded from pinned host memory (what the reference's loop does per
     iteration, train_gan.py:119-124), the upload of launch i+1 overlapped with the graph of launch i."""
@@ -538,6 +634,7 @@ def main():
             extra("config4", lambda: config4_point(b, 200))
             extra("large_m", lambda: {"config5_shard_b128_k32": large_m_point(b, 128, 32, 60),
                                       "b1024_k6": large_m_point(b, 1024, 6, 60)})
+            extra("forward_model", lambda: forward_model_point(b, 0.0 if args.no_cpu_baseline else min(args.cpu_seconds, 8.0)))
     if world > 1 and b.p2p is not None:
         b.p2p.close()
     if rank != 0:
