@@ -38,3 +38,21 @@ tot = sum(v[0] for v in timed.values())
 print("per label (HIP events, 3 steps): total %.3f ms/step" % (tot / 3))
 for name, (ms, cnt) in sorted(timed.items(), key=lambda kv: -kv[1][0]):
     print("  %-28s %3d launches/step  %8.1f us each  %7.1f us/step %5.1f%%" % (name, cnt // 3, ms / cnt * 1e3, ms / 3 * 1e3, 100 * ms / tot))
+if os.environ.get("GRAPH"):
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        tr.step(cur, fut, act)
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        tr.step(cur, fut, act)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    print("graph replay: batch %d: %.3f ms/step" % (n, dt * 1e3))
