@@ -88,6 +88,17 @@ def sum_all_reduce(group=None):
     return reduce_fn
 
 
+def mean_all_reduce(world, group=None):
+    """reduce_fn for ForwardModelTrainer: in-place MEAN all-reduce of a flat gradient -- every rank's loss is the mean over
+    its own shard (train_forward_model.py:106-107), equal shards, so the mean of the ranks' gradients is the gradient of
+    the global-batch mean (what torch's DistributedDataParallel does; BatchNorm statistics stay per rank, as there
+    without SyncBatchNorm)."""
+    def reduce_fn(flat_grad):
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+        flat_grad.mul_(1.0 / world)
+    return reduce_fn
+
+
 def run_step(backend, reduce_fn, discrim_steps=1):
     """One training iteration in data-parallel order.  `backend` provides
     d_grads(first) -> flat D gradient, apply_d(grad), g_grads() -> flat G gradient, apply_g(grad)."""

@@ -9,7 +9,11 @@ What differs from the reference, on purpose:
   * the StepLR scheduler the reference constructs and never steps (train_forward_model.py:86) is not constructed;
   * visdom image panels are attempted only if visdom is importable;
   * `train_data_path: synthetic:<N>` gives seeded synthetic trajectories (the HDF5 loader needs h5py, see
-    utils/trajectory_loader.py).
+    utils/trajectory_loader.py);
+  * more than one process (torch.distributed.run) trains data-parallel: `batch_size` is the GLOBAL batch, every rank
+    takes batch_size / world_size trajectories of each (identically shuffled) batch, the flat gradient is averaged over
+    RCCL between backward and Adam (ndivplanning_amd/dp.py::mean_all_reduce).  BatchNorm statistics are per rank, as with
+    torch's DistributedDataParallel; a final batch that does not split evenly is dropped; rank 0 saves.
 The whole module is saved every `epochs_per_stage` epochs as the reference does (train_forward_model.py:151-163), after
 the trainer's flat vectors are written back into it."""
 import importlib
@@ -21,6 +25,7 @@ import numpy as np
 import torch
 from torch.utils import data
 
+from . import dp
 from .forward_trainer import ForwardModelTrainer
 from .models.forward_encoder import Decoder, Encoder, ForwardAutoencoder
 from .train_gan import _get, denorm, make_dataset, norm  # noqa: F401
@@ -53,11 +58,19 @@ def train(config):
     random_seed = int(config.random_seed)
     lr_rate, num_epochs, batch_size = float(f.learning_rate), int(f.num_epochs), int(f.batch_size)
     epochs_per_stage = int(f.epochs_per_stage)
-    device = torch.device(config.gpu_id if torch.cuda.is_available() else "cpu")
-    if device.type != "cuda":
+    rank, world, local_rank = dp.env_world()
+    if not torch.cuda.is_available():
         from . import _capi
-        raise _capi.NdpError("train_forward_model needs a ROCm GPU (gpu_id %r resolves to %s); there is no CPU path"
-                             % (config.gpu_id, device))
+        raise _capi.NdpError("train_forward_model needs a ROCm GPU (gpu_id %r); there is no CPU path" % (config.gpu_id,))
+    gpu = local_rank if world > 1 else config.gpu_id
+    if world > 1 and os.environ.get("NDP_BENCH_ONE_GPU") == "1":      # rehearsal: all ranks on one card
+        gpu = 0
+    device = torch.device("cuda", gpu) if isinstance(gpu, int) else torch.device(gpu)
+    torch.cuda.set_device(device)
+    dp.init_process_group(device)
+    if batch_size % world != 0:
+        raise ValueError("training.forward.batch_size=%d must be a multiple of the %d ranks" % (batch_size, world))
+    local_batch = batch_size // world
     bind_reference_class_paths()
     torch.manual_seed(random_seed)                                   # train_forward_model.py:60-61
     np.random.seed(random_seed)
@@ -77,7 +90,12 @@ def train(config):
     model.decoder.weight_init(mean=0.0, std=0.02)
     model.encoder.weight_init(mean=0.0, std=0.02)
     model.train()
-    trainer = ForwardModelTrainer(model, batch=batch_size, lr=lr_rate, betas=(0.5, 0.999))
+    if world > 1:                                                    # one set of initial weights: rank 0's
+        import torch.distributed as dist
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, src=0)
+    trainer = ForwardModelTrainer(model, batch=local_batch, lr=lr_rate, betas=(0.5, 0.999),
+                                  reduce_fn=dp.mean_all_reduce(world) if world > 1 else None)
 
     history = []
     step = 0
@@ -85,6 +103,11 @@ def train(config):
         trainer.loss_sum.zero_()
         pairs = 0
         for images, _, actions, _ in loader:
+            if world > 1:
+                if images.shape[0] != batch_size:                    # ragged final batch: does not split evenly
+                    continue
+                lo, hi = dp.shard_bounds(batch_size, rank, world)
+                images, actions = images[lo:hi], actions[lo:hi]
             images = images.to(device, non_blocking=True).float()
             actions = actions.to(device, non_blocking=True).float()
             for image_num in range(dataset.seq_length - 1):          # train_forward_model.py:98-112
@@ -93,16 +116,19 @@ def train(config):
                 step += 1
                 pairs += 1
         avg_loss = float(trainer.loss_sum.item()) / max(pairs, 1)    # (seq_length - 1) * len(loader) terms
+        if world > 1:
+            avg_loss = dp.reduce_loss_shares([avg_loss / world], device=device)[0]
         history.append(avg_loss)
         if display is not None:                                      # pragma: no cover
             display.plot("loss", "train", "Forward Model Loss", epoch, avg_loss)
         logging.info("{}, {}: reconstruction loss per epoch: {}".format(epoch, step, avg_loss))
-        if epoch % epochs_per_stage == epochs_per_stage - 1:          # train_forward_model.py:151-163
+        if epoch % epochs_per_stage == epochs_per_stage - 1 and rank == 0:   # train_forward_model.py:151-163
             os.makedirs(config.forward_save_path, exist_ok=True)
             trainer.sync_to_module()
             torch.cuda.synchronize(device)
             torch.save(model, os.path.join(config.forward_save_path, "forward_autoencoder_{}.pt".format(str(epoch))))
     trainer.sync_to_module()
+    train.last_trainer = trainer                                       # tests: the replica's flat vectors
     return history
 
 

@@ -107,3 +107,29 @@ def test_two_ranks_equal_global_batch(tmp_path, dsteps):
         err = (a - b).abs()
         assert err.max() <= 2.5 * 2e-4 * steps * dsteps, name
         assert (err > 1e-4).float().mean() <= 0.06, name
+
+
+def _mean_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from ndivplanning_amd import dp
+    dp.init_process_group(None)
+    lo, hi = dp.shard_bounds(8, rank, world)
+    grad = torch.arange(6, dtype=torch.float32) * (rank + 1) + lo          # what a rank's backward left in its flat vector
+    dp.mean_all_reduce(world)(grad)
+    torch.save({"grad": grad, "bounds": (lo, hi)}, os.path.join(out_dir, "mean%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_mean_all_reduce_of_the_forward_model_recipe(tmp_path):
+    """The forward model's data-parallel exchange (train_forward_model.py mirror): every rank ends up with the MEAN of the
+    ranks' flat gradients, in place."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_mean_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = (torch.load(os.path.join(str(tmp_path), "mean%d.pt" % r)) for r in range(2))
+    want = (torch.arange(6, dtype=torch.float32) * 1 + 0 + torch.arange(6, dtype=torch.float32) * 2 + 4) / 2
+    assert torch.equal(a["grad"], want) and torch.equal(b["grad"], want)
+    assert a["bounds"] == (0, 4) and b["bounds"] == (4, 8)

@@ -2,6 +2,7 @@
 the oracle's restatement of models/forward_encoder.py + train_forward_model.py:98-112 and with the golden vector the
 REFERENCE's own ForwardAutoencoder / MSELoss / Adam produced (tests/golden/forward_model_case.npz)."""
 import io
+import os
 
 import numpy as np
 import pytest
@@ -292,3 +293,88 @@ def test_train_script_epoch_matches_an_oracle_replay(tmp_path):
         assert float(diff.mean()) <= 0.05 * LR, (name, float(diff.mean()))
     np.testing.assert_allclose(saved.state_dict()["decoder.deconv5_bn.running_var"].cpu().numpy(),
                                state["decoder.deconv5_bn.running_var"].numpy(), rtol=1e-3)
+
+
+def _fm_rank_main(rank, world, port, cfg_dict, out_dir):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", NDP_DIST_BACKEND="gloo", NDP_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from ndivplanning_amd import train_forward_model as script
+    from ndivplanning_amd.utils.file import AttrDict
+    initial = {}
+    real_trainer = script.ForwardModelTrainer
+
+    def spy(model, **kw):
+        initial.update({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+        return real_trainer(model, **kw)
+    script.ForwardModelTrainer = spy
+    hist = script.train(AttrDict(cfg_dict))
+    tr = script.train.last_trainer
+    torch.save({"params": tr.params.cpu(), "stats": tr.stats.cpu(), "hist": hist, "initial": initial,
+                "named": {k: v.cpu() for k, v in tr.named_parameters().items()}}, os.path.join(out_dir, "fm_rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_average_their_gradients(tmp_path):
+    """train_forward_model.train under two processes (both on cuda:0, gloo): each rank takes half of every global batch,
+    the flat gradient is averaged between backward and Adam, BatchNorm statistics stay per rank (torch DDP's recipe).
+    Replicas must stay bit-identical; the result must be what the oracle gives when it is driven the same way."""
+    import socket
+    import torch.multiprocessing as mp
+    from ndivplanning_amd.train_gan import make_dataset
+    from ndivplanning_amd.utils.file import AttrDict
+    torch.set_num_threads(8)
+    cfg = {"random_seed": 0, "train_data_path": "synthetic:4:images", "gpu_id": 0, "trajectory_length": 3,
+           "forward_save_path": str(tmp_path / "fm"),
+           "training": {"forward": {"num_epochs": 1, "learning_rate": LR, "report_feq": 10, "batch_size": 4,
+                                    "epochs_per_stage": 1, "step_lr_gamma": 0.1}}}
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_fm_rank_main, args=(2, port, cfg, str(tmp_path)), nprocs=2, join=True)
+    res = [torch.load(str(tmp_path / ("fm_rank%d.pt" % r))) for r in range(2)]
+    assert torch.equal(res[0]["params"], res[1]["params"])                 # replicas in lockstep
+    assert not torch.equal(res[0]["stats"], res[1]["stats"])               # BatchNorm statistics are each rank's own
+    assert res[0]["hist"] == res[1]["hist"] and len(res[0]["hist"]) == 1
+    assert all(torch.equal(res[0]["initial"][k], res[1]["initial"][k]) for k in res[0]["initial"])
+    assert os.path.isfile(str(tmp_path / "fm" / "forward_autoencoder_0.pt"))
+    # ---- the same thing with the oracle: shared parameters, one set of BatchNorm buffers per rank
+    acfg = AttrDict(cfg)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    from ndivplanning_amd.models import forward_encoder as FE
+    FE.ForwardAutoencoder()                                                # the CPU stream position of the run
+    ds = make_dataset(acfg)
+    loader = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=True)
+    state = {k: v.clone() for k, v in res[0]["initial"].items()}
+    names = FO.trainable(state)
+    used = [n for n in names if not n.startswith(("encoder.conv4_bn", "encoder.conv5_bn"))]
+    for n in used:
+        state[n].requires_grad_(True)
+    opt = torch.optim.Adam([state[n] for n in used], lr=LR, betas=(0.5, 0.999))
+    views = [state, dict(state)]
+    for k in state:
+        if "running_" in k or "num_batches" in k:
+            views[1][k] = state[k].clone()
+    losses = []
+    for images, _, actions, _ in loader:
+        for i in range(ds.seq_length - 1):
+            grads, step_loss = None, 0.0
+            for r in range(2):
+                cur, fut, act = images[2 * r:2 * r + 2, i], images[2 * r:2 * r + 2, i + 1], actions[2 * r:2 * r + 2, i]
+                loss = torch.nn.functional.mse_loss(FO.forward(views[r], cur, act, training=True), fut - cur)
+                g = torch.autograd.grad(loss, [state[n] for n in used])
+                grads = list(g) if grads is None else [a + b for a, b in zip(grads, g)]
+                step_loss += loss.item() / 2
+            for n, g in zip(used, grads):
+                state[n].grad = g / 2
+            opt.step()
+            losses.append(step_loss)
+    assert abs(res[0]["hist"][0] - sum(losses) / len(losses)) <= 5e-5
+    for name in ("decoder.deconv2.weight", "encoder.conv5.weight", "decoder.conv_refine_1.weight"):
+        diff = (res[0]["named"][name] - state[name].detach()).abs()
+        assert float(diff.mean()) <= 0.05 * LR, (name, float(diff.mean()))
