@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NDP_VERSION 130          /* 0.3.0: ndp_fm_* (forward / next-frame model) */
+#define NDP_VERSION 131          /* 0.3.1: ndp_fm_* (forward / next-frame model), ndp_fm_backward */
 
 #define NDP_OK            0
 #define NDP_E_ARG         1      /* bad argument (shape, alignment, null) */
@@ -318,6 +318,9 @@ int ndp_encoder_forward(const float *packed_params, const float *images, int64_t
  *   ndp_fm_train_grads  replaces  loss = mse(model(cur, a), fut - cur); zero_grad(); loss.backward()
  *                       (train_forward_model.py:102-109): loss[0] = the MSE, *loss_sum += it (NULL: not kept),
  *                       grad = every gradient, resid_out (NULL or [n,3,128,128]) = the prediction
+ *   ndp_fm_backward     replaces  loss.backward() for ANY loss of the residual: d_resid [n,3,128,128] = d loss / d
+ *                       residual; must follow ndp_fm_forward(training != 0) on the same n images with the same workspace
+ *                       and nothing in between (the activations live there); grad = every gradient
  *   ndp_fm_apply_adam   replaces  optimizer.step() (:110) for the flat parameter vector, and rebuilds the
  *                       second weight order in the workspace (step_count: the Adam state word of ndp_adam_step)
  * Images [n,3,128,128] NCHW and actions [n,4] as the reference's loader delivers them.
@@ -349,6 +352,8 @@ int ndp_fm_train_grads(const float *params, float *running_stats, const float *s
                        const float *state_fut, const float *actions, int64_t n_images,
                        float *grad, float *loss, float *loss_sum, float *resid_out,
                        float *workspace, void *stream);
+int ndp_fm_backward(const float *params, const float *d_resid, int64_t n_images, float *grad,
+                    float *workspace, void *stream);
 int ndp_fm_apply_adam(float *params, const float *grad, float *exp_avg, float *exp_avg_sq,
                       int32_t *step_count, float lr, float beta1, float beta2, float eps,
                       float *workspace, void *stream);

@@ -8,12 +8,16 @@ Same class names, constructor order (so that `torch.manual_seed(s); ForwardAutoe
 parameters), attribute names and state_dict keys as the reference, so that its whole-module pickles load with
 `ndivplanning_amd.train_forward_model.bind_reference_class_paths()`.
 
-Where the arithmetic runs: a forward on a ROCm GPU without autograd recording (eval mode as control_evaluation.py /
-mpc_eval.py call it, or training mode under no_grad) goes through `ndp_fm_forward` (csrc/ndp_forward_model.inc:
-implicit-GEMM convolutions, transposed convolutions as four parity classes, BatchNorm as a statistics + an
-elementwise pass).  Training goes through `ndivplanning_amd.forward_trainer.ForwardModelTrainer`, which owns the flat
-parameter vector the kernels read and runs forward, loss, backward and Adam in HIP.  A forward that records autograd
-history keeps PyTorch's operators, so that the classes still behave like nn.Modules there."""
+Where the arithmetic runs: every `ForwardAutoencoder.forward` on a ROCm GPU goes through `ndp_fm_forward`
+(csrc/ndp_forward_model.inc: implicit-GEMM convolutions, transposed convolutions as four parity classes, BatchNorm as a
+statistics + an elementwise pass) -- eval mode as control_evaluation.py / mpc_eval.py call it, training mode under
+no_grad, and training mode WITH autograd recording, where the residual carries a grad_fn whose backward is
+`ndp_fm_backward` (the reference's own loop, `loss = mse(model(cur, a), fut - cur); loss.backward(); optimizer.step()`,
+train_forward_model.py:102-110, runs unchanged, with torch's optimizer on the module's parameters).  The fast way to
+train is `ndivplanning_amd.forward_trainer.ForwardModelTrainer`, which owns the flat parameter vector the kernels read
+and runs forward, loss, backward and Adam in HIP without repacking.  There is no CPU path and no gradient with respect
+to the images or actions (the reference never asks for one): both raise.  `Encoder` / `Decoder` called on their own
+(nobody in the reference does) keep PyTorch's operators."""
 import ctypes
 
 import torch
@@ -184,6 +188,36 @@ def unpack_into_module(model, params, stats=None, batches_tracked=None):
                     bn.num_batches_tracked.fill_(int(batches_tracked))
 
 
+class _TrainingForward(torch.autograd.Function):
+    """residual = model(state_cur, actions) in training mode, differentiable with respect to the model's parameters:
+    forward = ndp_fm_forward (batch-statistics BatchNorm, running statistics moved), backward = ndp_fm_backward.
+    The parameters are passed as inputs so that autograd routes their gradients; their order is `names`."""
+
+    @staticmethod
+    def forward(ctx, model, state_cur, actions, names, *params):
+        out = model._forward_hip(state_cur, actions)
+        ctx.model, ctx.names, ctx.n = model, names, int(state_cur.shape[0])
+        ctx.serial = model.__dict__["_ndp_cache"]["serial"]
+        return out
+
+    @staticmethod
+    def backward(ctx, d_resid):
+        model = ctx.model
+        lib = _capi.load()
+        cache = model.__dict__.get("_ndp_cache")
+        if cache is None or cache.get("serial") != ctx.serial or cache.get("consumed"):
+            raise _capi.NdpError("backward through a ForwardAutoencoder forward whose activations are gone: another forward "
+                                 "of the same module ran in between (one forward, one backward, as the reference's loop)")
+        d = d_resid.detach().contiguous().float()
+        grad = torch.empty_like(cache["params"])
+        with _capi.on_device(d):
+            _capi.check(lib.ndp_fm_backward(_capi.ptr(cache["params"]), _capi.ptr(d), ctx.n, _capi.ptr(grad), _capi.ptr(cache["ws"]),
+                                            _capi.stream_ptr(d.device)), "ndp_fm_backward")
+        cache["consumed"] = True
+        by_name = unpack_vector(grad, model)
+        return (None, None, None, None) + tuple(by_name.get(n) for n in ctx.names)
+
+
 class ForwardAutoencoder(nn.Module):
     def __init__(self):
         super().__init__()
@@ -221,6 +255,7 @@ class ForwardAutoencoder(nn.Module):
         x = state_cur.detach().contiguous().float()
         a = actions.detach().contiguous().float()
         out = torch.empty_like(x)
+        cache["serial"], cache["consumed"] = cache.get("serial", 0) + 1, False     # which forward the workspace holds
         with _capi.on_device(x):
             st = _capi.stream_ptr(dev)
             if not cache["packed"]:
@@ -240,13 +275,16 @@ class ForwardAutoencoder(nn.Module):
         return out
 
     def forward(self, state_cur, actions):
-        records = torch.is_grad_enabled() and (state_cur.requires_grad or actions.requires_grad or
-                                               (self.training and any(p.requires_grad for p in self.parameters())))
-        if records:
-            return self._forward_torch(state_cur, actions)
         if not state_cur.is_cuda:
             raise _capi.NdpError("state_cur is on %s: ForwardAutoencoder computes only on a ROCm GPU (no CPU fallback)"
                                  % state_cur.device)
         if actions.device != state_cur.device:
             raise _capi.NdpError("state_cur is on %s, actions on %s" % (state_cur.device, actions.device))
+        if torch.is_grad_enabled() and (state_cur.requires_grad or actions.requires_grad):
+            raise NotImplementedError("ForwardAutoencoder gives no gradient with respect to its inputs (the reference "
+                                      "never asks for one)")
+        named = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
+        if torch.is_grad_enabled() and self.training and named:
+            # the reference's own training loop: the residual gets a grad_fn whose backward is the HIP backward pass
+            return _TrainingForward.apply(self, state_cur, actions, tuple(n for n, _ in named), *[p for _, p in named])
         return self._forward_hip(state_cur, actions)

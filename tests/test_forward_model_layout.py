@@ -68,9 +68,11 @@ def test_host_side_refusals(lib):
     from ndivplanning_amd.forward_trainer import ForwardModelTrainer
     with pytest.raises(_capi.NdpError):
         ForwardModelTrainer(model, batch=2)
-    # a forward that records autograd history keeps the module's operators (same arithmetic as the oracle)
     model.train()
     x, a = torch.rand(1, 3, 128, 128) * 2 - 1, torch.rand(1, 4)
-    y = model(x, a)
+    with pytest.raises(_capi.NdpError):                                  # training mode neither
+        model(x, a)
+    # the operator composition the mirror keeps for Encoder / Decoder called on their own is the oracle's arithmetic
+    y = model._forward_torch(x, a)
     want = FO.forward({k: v.clone() for k, v in model.state_dict().items()}, x, a, training=True)
     assert y.requires_grad and float((y.detach() - want).abs().max()) <= 1e-6

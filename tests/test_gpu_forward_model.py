@@ -378,3 +378,47 @@ def test_two_ranks_on_one_gpu_average_their_gradients(tmp_path):
     for name in ("decoder.deconv2.weight", "encoder.conv5.weight", "decoder.conv_refine_1.weight"):
         diff = (res[0]["named"][name] - state[name].detach()).abs()
         assert float(diff.mean()) <= 0.05 * LR, (name, float(diff.mean()))
+
+
+def test_the_reference_loop_unchanged_module_forward_loss_backward_torch_adam():
+    """train_forward_model.py:102-110 as written -- `resid = model(cur, a); loss = mse(resid, fut - cur);
+    optimizer.zero_grad(); loss.backward(); optimizer.step()` -- with the mirror module and torch's own Adam: the residual's
+    grad_fn runs the HIP backward pass (ndp_fm_backward), gradients arrive in the parameters' .grad in the module's layouts."""
+    from ndivplanning_amd.models import forward_encoder as FE
+    torch.set_num_threads(8)
+    n = 2
+    state = FO.init_forward_model_state(41)
+    model = FE.ForwardAutoencoder()
+    model.load_state_dict(state)
+    model = model.to(DEV).train()
+    mse = torch.nn.MSELoss()
+    opt = torch.optim.Adam([{"params": model.decoder.parameters()}, {"params": model.encoder.parameters()}], lr=LR,
+                           betas=(0.5, 0.999))
+    oracle = FO.ForwardModelTrainer(state, lr=LR)
+    frames, actions = _inputs(42, n)
+    for it in range(2):
+        cur, fut, act = (t.contiguous().to(DEV) for t in (frames[:, it], frames[:, it + 1], actions[:, it]))
+        resid = model(cur, act)
+        assert resid.requires_grad and resid.grad_fn is not None
+        loss = mse(resid, fut - cur)
+        opt.zero_grad()
+        loss.backward()
+        want = oracle.step(frames[:, it].contiguous(), frames[:, it + 1].contiguous(), actions[:, it].contiguous())
+        assert abs(loss.item() - want["loss"].item()) <= (1e-5 if it == 0 else 2e-4)
+        if it == 0:
+            for name, p in model.named_parameters():
+                ref = want["grads"][name]
+                if ref is None:
+                    assert p.grad is None, name               # conv4_bn / conv5_bn: never applied
+                elif name not in NOISE_BIASES:
+                    assert _rel(p.grad.cpu(), ref) <= 2e-2, (name, _rel(p.grad.cpu(), ref))   # flip-tolerant, see above
+        opt.step()
+    assert int(model.decoder.deconv4_bn.num_batches_tracked) == 2
+    with pytest.raises(NotImplementedError):
+        model(frames[:, 0].to(DEV).requires_grad_(True), actions[:, 0].to(DEV))
+    # a second forward invalidates the first one's activations: its backward must refuse, not compute garbage
+    r1 = model(frames[:, 0].to(DEV), actions[:, 0].to(DEV))
+    model(frames[:, 1].to(DEV), actions[:, 1].to(DEV))
+    from ndivplanning_amd import _capi
+    with pytest.raises(_capi.NdpError):
+        r1.sum().backward()
