@@ -103,17 +103,17 @@ elif which == "pa":
           % tuple(np.median(w0[:, b] - w0[:, a_]) / 100 for a_, b in ((0, 24), (24, 25), (25, 26), (26, 1))))
     print("role 0, tail: store h4 %.2f us | fc5 (VALU) %.2f | barrier + rest %.2f"
           % tuple(np.median(w0[:, b] - w0[:, a_]) / 100 for a_, b in ((15, 22), (22, 23), (23, 2))))
-    if 128 < nt and nt + (nt + 1) // 2 <= 256:
-        s = stamps.cpu().numpy().reshape(-1, 32, 2)[nt:nt + (nt + 1) // 2]
-        wall = s[:, :, 1].astype(np.float64)
-        all_ = stamps.cpu().numpy().reshape(-1, 32, 2)[:nt + (nt + 1) // 2][:, :, 1].astype(np.float64)
-        t0 = all_[:, 0].min()
-        print("role 1 (paired real tiles): start median %.2f us after first start, end median %.2f (max %.2f); D fc1 done at %.2f, fwd done %.2f"
-              % (np.median(wall[:, 0] - t0) / 100, np.median(wall[:, 8] - t0) / 100, (wall[:, 8] - t0).max() / 100,
+    nr = (codes.shape[0] + 15) // 16                       # role 1: one workgroup per tile of the FLAT distinct real rows
+    if nr > 0:
+        both = stamps.cpu().numpy().reshape(-1, 32, 2)[:nt + nr][:, :, 1].astype(np.float64)
+        t0 = both[:, 0].min()
+        wall = both[nt:]
+        print("role 1 (%d tiles of distinct real rows): start median %.2f us after first start, end median %.2f (max %.2f); D fc1 done at %.2f, fwd done %.2f"
+              % (nr, np.median(wall[:, 0] - t0) / 100, np.median(wall[:, 8] - t0) / 100, (wall[:, 8] - t0).max() / 100,
                  np.median(wall[:, 3] - t0) / 100, np.median(wall[:, 4] - t0) / 100))
-        print("role 1 stages: prologue (ring issue, 2 code tiles, actions, barrier) %.2f us | D fc1 %.2f | barrier %.2f | fc2+fc3 %.2f | fc4+loss %.2f | stores %.2f | narrow+dg3 %.2f | dg2+seg+stores %.2f"
+        print("role 1 stages: prologue (ring issue, code tile, actions, barrier) %.2f us | D fc1 %.2f | barrier %.2f | fc2+fc3 %.2f | fc4+loss %.2f | stores %.2f | narrow+dg3 %.2f | dg2+stores %.2f"
               % tuple(np.median(wall[:, b] - wall[:, a_]) / 100 for a_, b in ((0, 10), (10, 11), (11, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8))))
-        r0 = all_[:nt]
+        r0 = both[:nt]
         print("role 0: end median %.2f us (max %.2f)" % (np.median(r0[:, 8] - t0) / 100, (r0[:, 8] - t0).max() / 100))
 elif which == "pb":
     tr._phase_a(True)
