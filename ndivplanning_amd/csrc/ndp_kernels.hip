@@ -716,8 +716,11 @@ __device__ __forceinline__ void phase_a_d_part(const PhaseAArgs& a, bool real, i
   store_tile<1, 256>(a.dy3 + g0 * 256, 256, XC, 260);
 }
 
+#ifndef NDP_PHASE_A_SMALL_RING
+#define NDP_PHASE_A_SMALL_RING 24     // 32 needs 36 bytes of scratch per lane under the 168-VGPR cap of three workgroups per CU;
+#endif                                // 24: none, and 0.7 - 1 % of the large-M step (B = 1024 / K = 6: 0.5325 -> 0.5288 ms)
 // RG = VGPR budget of each weight prefetch ring: 96 keeps a lone workgroup per CU streaming (grids of up to 256
-// workgroups); 32 with a tighter register cap lets several workgroups share a CU at large M.
+// workgroups); a small one (phase A 24, phase B 32) with a tighter register cap lets several workgroups share a CU at large M.
 template <bool PK, int RG>
 __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 3)) void k_phase_a(PhaseAArgs a_segment) {
   // one workgroup per CU (RG = 96): nothing hides the argument loads, read them in one round trip (load_kernargs);
