@@ -665,6 +665,10 @@ def main():
                    "last_losses": {"D": losses[0], "G": losses[1], "ndiv": losses[2]}},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                     # the same launch priced at the reference's work (D's real pass on all M rows, as round 1 counted it
+                     # before the real pass was deduplicated): comparable across rounds
+                     "achieved_reference_equivalent": round(achieved * kernel_macs(1)[0][dom] / table[dom], 3),
+                     "frac_reference_equivalent": round(achieved * kernel_macs(1)[0][dom] / table[dom] / MFMA_F32_PEAK_TFLOPS, 4),
                      "traffic": PMC_HBM_BYTES_DEFAULT.get(dom) if (batch, k) == (64, 6) else None,
                      "traffic_source": PMC_SOURCE,
                      "algorithmic_flops_per_launch": dom_flops,
