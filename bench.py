@@ -427,12 +427,14 @@ def forward_model_point(b, cpu_seconds):
             torch.cuda.synchronize(b.dev)
             reps.append(ev[0].elapsed_time(ev[1]) / steps)
         ms = statistics.median(reps)
+        was = _capi.load().ndp_fm_side_stream(0)               # one stream: the per-launch durations do not overlap
         _capi.timing_enable(True)
         for _ in range(3):
             tr.step(cur, fut, act)
         torch.cuda.synchronize(b.dev)
         timed = _capi.timing_collect()
         _capi.timing_enable(False)
+        _capi.load().ndp_fm_side_stream(was)
         groups = {}
         for name, (tot, cnt) in timed.items():
             key = name.split("[")[0]

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NDP_VERSION 131          /* 0.3.1: ndp_fm_* (forward / next-frame model), ndp_fm_backward */
+#define NDP_VERSION 132          /* 0.3.2: ndp_fm_* (forward / next-frame model), ndp_fm_backward, ndp_fm_side_stream */
 
 #define NDP_OK            0
 #define NDP_E_ARG         1      /* bad argument (shape, alignment, null) */
@@ -352,6 +352,10 @@ int ndp_fm_train_grads(const float *params, float *running_stats, const float *s
                        const float *state_fut, const float *actions, int64_t n_images,
                        float *grad, float *loss, float *loss_sum, float *resid_out,
                        float *workspace, void *stream);
+/* The weight gradients of the backward pass run on a stream of the library's own beside the caller's (fork / join by
+ * events, capturable); ndp_fm_side_stream(0) keeps every launch on the caller's stream (per-kernel timing), returns the
+ * previous setting. */
+int ndp_fm_side_stream(int on);
 int ndp_fm_backward(const float *params, const float *d_resid, int64_t n_images, float *grad,
                     float *workspace, void *stream);
 int ndp_fm_apply_adam(float *params, const float *grad, float *exp_avg, float *exp_avg_sq,

@@ -17,7 +17,7 @@ ACTION_DIM = 4
 MAX_NOISE_DIM = 16
 MAX_SAMPLES = 256
 ROW_PAD = 32
-EXPECTED_VERSION = 131          # NDP_VERSION of include/ndp.h this binding was written against
+EXPECTED_VERSION = 132          # NDP_VERSION of include/ndp.h this binding was written against
 
 _lib = None
 
@@ -108,6 +108,7 @@ SIGNATURES = {
     "ndp_fm_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "ndp_fm_train_grads": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),
+    "ndp_fm_side_stream": (c_int, [c_int]),
     "ndp_fm_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "ndp_fm_apply_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                                   c_void_p, c_void_p]),
