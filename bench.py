@@ -518,6 +518,8 @@ def main():
     m = flat * k
     graph_ok = not args.no_graph
     spl = args.steps_per_launch if (b.reduce_fn is None and graph_ok) else 1
+    if spl > 1 and args.steps % spl != 0 and args.steps <= 3 * spl:
+        spl = args.steps          # a short bracket that is not a multiple of the default: one graph of exactly K steps
     tr = b.make_trainer(batch, k, flat * world, spl, b.p2p, b.reduce_fn, use_graph=graph_ok)
 
     # step-0 parity figure (outside the timed region): NDiv / losses vs the oracle on rank 0's shard

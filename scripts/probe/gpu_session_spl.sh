@@ -1,6 +1,6 @@
 export TMPDIR=/tmp
-for spl in 8 16 32 64; do
-python bench.py --steps 1920 --warmup 192 --steps-per-launch $spl --no-extras --no-cpu-baseline 2>/dev/null | python -c "
+for i in 1 2 3; do
+python bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('spl $spl', d['value'], d['ms_per_step'])"
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('driver-like', d['value'], d['ms_per_step'], d['config']['steps_per_graph_launch'], d['config']['repeats'])"
 done
