@@ -638,49 +638,78 @@ constexpr int phase_a_lds_floats() {
   return 16 * (260 + TAILLD + 132 + 68 + 2) + 16 * 260 + 16 * 4 + 8 + kSW5 + kSW4;
 }
 
-// ---- K % 16 == 0: the 16 rows of a tile are samples of ONE flat row and share its code.  The 256 code columns of G.fc1
-// and of D.fc1 then contribute the same value to all 16 rows: one dot product per output column (VALU, ~128 FMAs per
-// thread) instead of 16 k-steps on the matrix pipe, and the layer's output is that row plus the narrow tail (noise /
-// action columns) -- no MFMA at all for fc1.  (DD variants of the phase kernels; 27 % of phase A's MFMAs, 10 % of phase
-// B's.)
-// part[p][o] = sum over segment p of the code row of W[o][.] * code[.]   (PARTS = 256 threads / OUT segments).  W is read
-// from the layer's forward-packed copy (fwd_pack_offset): the 4 consecutive k of one (t, q) are 16 bytes, and the 16
-// output columns of a tile sit 16 bytes apart -- a wave's load covers four 256-byte spans (row-major W would be 64
-// different cache lines per load: measured 4 % of the kernel instead of the 10 % the removed MFMAs are).
-template <int OUT>
-__device__ __forceinline__ void code_row_dot(const float* __restrict__ Wpacked, const float* code, float* part) {
+// ---- The K rows of a flat row share its code (the reference repeats it K times, train_gan.py:140-156), so a 16-row tile
+// holds few DISTINCT code rows: 1 when K % 16 == 0, at most 4 when K >= 6 (floor(15 / K) + 2).  The 256 code columns of
+// G.fc1 and of D.fc1 then need one dot product per output column and DISTINCT code row -- on the VALU, 128 FMAs per
+// thread and code row, the weights read once for all rows -- instead of 16 k-steps of the matrix pipe over 16 rows, and
+// the layer's output is the row's product plus the narrow tail (noise / action columns): no MFMA at all for fc1.
+// (NR variants of the phase kernels: NR = number of code rows carried per tile, 0 = the MFMA path.  27 % of phase A's
+// MFMAs, 10 % of phase B's.)
+// part[(j * PARTS + p) * OUT + o] = sum over segment p of code row j of W[o][.] * code_j[.]   (PARTS = 256 threads / OUT).
+// W is read from the layer's forward-packed copy (fwd_pack_offset): the 4 consecutive k of one (t, q) are 16 bytes, and
+// the 16 output columns of a tile sit 16 bytes apart -- a wave's load covers four 256-byte spans (row-major W would be
+// 64 different cache lines per load: measured 2.8 % instead of 4.9 % at config 5).  `code`: NR rows of stride 260 in LDS.
+template <int OUT, int NR>
+__device__ __forceinline__ void code_rows_dot(const float* __restrict__ Wpacked, const float* code, float* part) {
   constexpr int PARTS = kThreads / OUT, SEG = CODE / PARTS;
   const int o = threadIdx.x % OUT, p = threadIdx.x / OUT;
-  const float* w = Wpacked + fwd_pack_offset(o, p * SEG, CODE, OUT);      // + 1024 floats per k-step t, + 64 per q
+  const float* w = Wpacked + fwd_pack_offset(o, p * SEG, CODE, OUT);      // + 256 floats per k-step t, + 64 per q
   const float* cr = code + p * SEG;
-  float s0 = 0.f, s1 = 0.f;
-#pragma unroll 4
+  float s0[NR], s1[NR];
+#pragma unroll
+  for (int j = 0; j < NR; ++j) s0[j] = s1[j] = 0.f;
+#pragma unroll 2
   for (int t = 0; t < SEG / 16; ++t) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4 wv = *reinterpret_cast<const f32x4*>(w + t * 256 + q * 64);
-      const f32x4 cv = *reinterpret_cast<const f32x4*>(cr + 16 * t + 4 * q);
-      s0 = fmaf(wv[0], cv[0], s0); s1 = fmaf(wv[1], cv[1], s1);
-      s0 = fmaf(wv[2], cv[2], s0); s1 = fmaf(wv[3], cv[3], s1);
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const f32x4 cv = *reinterpret_cast<const f32x4*>(cr + j * 260 + 16 * t + 4 * q);
+        s0[j] = fmaf(wv[0], cv[0], s0[j]); s1[j] = fmaf(wv[1], cv[1], s1[j]);
+        s0[j] = fmaf(wv[2], cv[2], s0[j]); s1[j] = fmaf(wv[3], cv[3], s1[j]);
+      }
     }
   }
-  part[p * OUT + o] = s0 + s1;
+#pragma unroll
+  for (int j = 0; j < NR; ++j) part[(j * PARTS + p) * OUT + o] = s0[j] + s1[j];
 }
-// Y[r][o] = act(bias[o] + the PARTS partial sums of code_row_dot + sum_j XT[r][j] * Wt[o][j]) for the 16 rows of the tile
-template <int OUT, int ACT>
-__device__ __forceinline__ void fc1_from_code_row(const float* part, const float* __restrict__ bias,
-                                                  const float* __restrict__ Wt, int ldw, int ntail,
-                                                  const float* XT, float* Y, int ldy) {
+// the tile's NR code rows (flat rows f0 .. f0 + NR - 1, zeros past the last one) -> LDS rows of stride 260
+template <int NR>
+__device__ __forceinline__ void load_code_rows(float* XC, const float* __restrict__ code, int64_t f0, int64_t nflat) {
+  const int j = threadIdx.x >> 6, c4 = threadIdx.x & 63;
+  if (j < NR) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (f0 + j < nflat) v = *reinterpret_cast<const f32x4*>(code + (size_t)(f0 + j) * CODE + 4 * c4);
+    *reinterpret_cast<f32x4*>(XC + j * 260 + 4 * c4) = v;
+  }
+}
+// Y[r][o] = act(bias[o] + the PARTS partial sums of row r's code row + sum_j XT[r][j] * Wt[o][j]) for the tile's 16 rows;
+// row r's code row = (rem0 + r) / K, rem0 = row0 % K, clamped to NR - 1 (rows past M: masked later, only finite here)
+template <int OUT, int ACT, int NR>
+__device__ __forceinline__ void fc1_from_code_rows(const float* part, const float* __restrict__ bias,
+                                                   const float* __restrict__ Wt, int ldw, int ntail,
+                                                   const float* XT, float* Y, int ldy, int rem0, int K) {
   constexpr int PARTS = kThreads / OUT, RSTEP = kThreads / OUT;
   const int o = threadIdx.x % OUT, r0 = threadIdx.x / OUT;
   float wt[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) wt[j] = j < ntail ? Wt[(size_t)o * ldw + j] : 0.f;
-  float base = bias[o];
+  float base[NR];
 #pragma unroll
-  for (int p = 0; p < PARTS; ++p) base += part[p * OUT + o];
+  for (int j = 0; j < NR; ++j) {
+    base[j] = bias[o];
+#pragma unroll
+    for (int p = 0; p < PARTS; ++p) base[j] += part[(j * PARTS + p) * OUT + o];
+  }
   for (int r = r0; r < 16; r += RSTEP) {
-    float s = base;
+    float s = base[0];
+    if (NR > 1) {
+      const int x = rem0 + r;
+      const int idx = (x >= K) + (x >= 2 * K) + (x >= 3 * K);
+#pragma unroll
+      for (int j = 1; j < NR; ++j) s = idx >= j ? base[j] : s;
+    }
 #pragma unroll
     for (int j = 0; j < 16; ++j)
       if (j < ntail) s = fmaf(XT[r * TAILLD + j], wt[j], s);
@@ -691,8 +720,9 @@ __device__ __forceinline__ void fc1_from_code_row(const float* part, const float
 // D forward + BCE + D backward data path on one 16-row tile whose inputs are in XC (codes) and XT (actions) and whose
 // fc1 weights `dw1` are already in flight.  real: the tile holds distinct real rows (weight real_scale each, stored
 // at row offset 0); otherwise fake rows (stored behind the rpad real rows).
-// DD (fake rows only): fc1 from the tile's code-row partial products `cpd` (see code_row_dot); `dw2` is then already in flight.
-template <bool PK, int RG, bool DD>
+// NR > 0 (fake rows only): fc1 from the tile's code-row partial products `cpd` (see code_rows_dot); `dw2` is then already
+// in flight.
+template <bool PK, int RG, int NR>
 __device__ __forceinline__ void phase_a_d_part(const PhaseAArgs& a, bool real, int tile, int ntiles,
                                                FwdW<256, 64, 4, PK, RG>& dw1, FwdW<64, 128, 4, PK, RG>& dw2, const float* cpd,
                                                float* XC, float* XT, float* B1,
@@ -706,8 +736,9 @@ __device__ __forceinline__ void phase_a_d_part(const PhaseAArgs& a, bool real, i
   const int64_t g0 = (real ? 0 : a.rpad) + row0;                  // row of this tile in the buffers k_wgrad reads
   // each layer's first weight fragments are issued inside the previous layer's k-loop (FwdW::preload_slice)
   NDP_STAMP(10);
-  if (DD) {
-    fc1_from_code_row<64, ACT_LRELU>(cpd, d.b1, d.w1, 260, ADIM, XT, B2, 68);            // D.h1 -> B2
+  if (NR > 0) {
+    fc1_from_code_rows<64, ACT_LRELU, (NR > 0 ? NR : 1)>(cpd, d.b1, d.w1, 260, ADIM, XT, B2, 68,
+                                                         (int)(row0 % a.code_rep), a.code_rep);   // D.h1 -> B2
   } else {
     dw2.bind(PK ? d.pf2 : d.w2, 64, d.b2, nullptr, 0);
     layer_fwd_run<1, 256, 64, ACT_LRELU, 4, PK>(dw1, XC, 260, B2, 68, XT, TAILLD, dw2);  // D.h1 -> B2
@@ -776,8 +807,10 @@ __device__ __forceinline__ void phase_a_d_part(const PhaseAArgs& a, bool real, i
 #endif                                // 24: none, and 0.7 - 1 % of the large-M step (B = 1024 / K = 6: 0.5325 -> 0.5288 ms)
 // RG = VGPR budget of each weight prefetch ring: 96 keeps a lone workgroup per CU streaming (grids of up to 256
 // workgroups); a small one (phase A 24, phase B 32) with a tighter register cap lets several workgroups share a CU at large M.
-template <bool PK, int RG, bool DD>
+template <bool PK, int RG, int NR>
 __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 3)) void k_phase_a(PhaseAArgs a_segment) {
+  constexpr bool DD = NR > 0;
+  constexpr int NRR = NR > 0 ? NR : 1;
   // one workgroup per CU (RG = 96): nothing hides the argument loads, read them in one round trip (load_kernargs);
   // with several workgroups per CU the registers that costs are worth more
   const PhaseAArgs a = (RG >= 96 && kFastKernargs) ? load_kernargs<PhaseAArgs>() : a_segment;
@@ -814,12 +847,8 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 3)) void k_phase_a(PhaseA
     const f32x4 w5r = *reinterpret_cast<const f32x4*>(g.w5 + 4 * threadIdx.x);
     const float b5r = g.b5[threadIdx.x & 3], w4r = d.w4[threadIdx.x], b4r = d.b4[0];
     NDP_STAMP(24);
-    if (DD) {                                            // the tile's ONE code row -> XC[0..255]
-      if (threadIdx.x < 64) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row0 < a.m) v = *reinterpret_cast<const f32x4*>(a.code + (size_t)((uint32_t)row0 / (uint32_t)a.code_rep) * CODE + 4 * threadIdx.x);
-        *reinterpret_cast<f32x4*>(XC + 4 * threadIdx.x) = v;
-      }
+    if (DD) {                                            // the tile's distinct code rows -> XC rows 0 .. NR-1
+      load_code_rows<NRR>(XC, a.code, (int64_t)((uint32_t)row0 / (uint32_t)a.code_rep), a.flat);
     } else {
       for (int idx = threadIdx.x; idx < R * 64; idx += kThreads) {
         const int i = idx >> 6, k = 4 * (idx & 63);
@@ -852,12 +881,14 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 3)) void k_phase_a(PhaseA
     __syncthreads();
     NDP_STAMP(1);
     // every layer's first weight fragments are issued inside the previous layer's k-loop (FwdW::preload_slice)
-    float* CPD = XC + 512;                               // DD: partial code-row products of G.fc1 (XC + 256) and D.fc1
+    float* CPG = XC + NRR * 260;                         // NR > 0: partial code-row products of G.fc1 [NR][2][128] ...
+    float* CPD = CPG + NRR * 256;                        // ... and of D.fc1 [NR][4][64], behind the code rows
     if (DD) {
-      code_row_dot<128>(g.pf1, XC, XC + 256);
-      code_row_dot<64>(d.pf1, XC, CPD);
+      code_rows_dot<128, NRR>(g.pf1, XC, CPG);
+      code_rows_dot<64, NRR>(d.pf1, XC, CPD);
       __syncthreads();
-      fc1_from_code_row<128, ACT_RELU>(XC + 256, g.b1, g.w1 + CODE, g.ld1, g.nz, XT, B1, 132);   // h1 -> B1
+      fc1_from_code_rows<128, ACT_RELU, NRR>(CPG, g.b1, g.w1 + CODE, g.ld1, g.nz, XT, B1, 132,
+                                             (int)(row0 % a.code_rep), a.code_rep);       // h1 -> B1
     } else {
       gw2.bind(PK ? g.pf2 : g.w2, 128, g.b2, nullptr, 0);
       layer_fwd_run<1, 256, 128, ACT_RELU, 2, PK>(gw1, XC, 260, B1, 132, XT, TAILLD, gw2); // h1 -> B1
@@ -908,7 +939,7 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 3)) void k_phase_a(PhaseA
     __syncthreads();
     NDP_STAMP(9);
     // ---------------- D on the fake rows
-    phase_a_d_part<PK, RG, DD>(a, false, tile, ntiles, dw1, dw2, CPD, XC, XT, B1, B2, L, DL, W4S, NDP_STAMP_PTR);
+    phase_a_d_part<PK, RG, NR>(a, false, tile, ntiles, dw1, dw2, CPD, XC, XT, B1, B2, L, DL, W4S, NDP_STAMP_PTR);
   } else {
     // ---------------- role 1: D on one tile of the distinct real rows
     const int tile = (int)blockIdx.x - ntiles;
@@ -929,7 +960,7 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 3)) void k_phase_a(PhaseA
       XT[idx] = (row < a.flat && t < ADIM) ? a.actions[row * ADIM + t] : 0.f;
     }
     __syncthreads();
-    phase_a_d_part<PK, RG, false>(a, true, tile, ntiles, dw1, dw2, nullptr, XC, XT, B1, B2, L, DL, W4S, NDP_STAMP_PTR);
+    phase_a_d_part<PK, RG, 0>(a, true, tile, ntiles, dw1, dw2, nullptr, XC, XT, B1, B2, L, DL, W4S, NDP_STAMP_PTR);
   }
   (void)red;
   NDP_STAMP(8);
@@ -962,8 +993,10 @@ constexpr int phase_b_lds_floats(bool pre) {
 // input tile, so the ~2.6 us round trip in the middle of the kernel (global -> LDS -> barrier, measured with
 // stamps) overlaps the D' half; with several workgroups per CU (large M) other workgroups hide it and the LDS
 // is better spent on residency.
-template <bool PK, int RG, bool PRE, bool DD>
+template <bool PK, int RG, bool PRE, int NR>
 __global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseBArgs a_segment) {
+  constexpr bool DD = NR > 0;
+  constexpr int NRR = NR > 0 ? NR : 1;
   const PhaseBArgs a = (RG >= 96 && kFastKernargs) ? load_kernargs<PhaseBArgs>() : a_segment;   // see k_phase_a
   constexpr int R = 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -990,13 +1023,9 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseB
 
   FwdW<256, 64, 4, PK, RG> dw1;
   FwdW<64, 128, 4, PK, RG> dw2;
-  if (DD) {                                              // one code row per tile (see code_row_dot): -> XC[0..255]
+  if (DD) {                                              // the tile's distinct code rows (see code_rows_dot) -> XC rows 0 .. NR-1
     dw2.preload(PK ? d.pf2 : d.w2, 64, d.b2, nullptr, 0);
-    if (threadIdx.x < 64) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row0 < a.m) v = *reinterpret_cast<const f32x4*>(a.code + (row0 / a.code_rep) * CODE + 4 * threadIdx.x);
-      *reinterpret_cast<f32x4*>(XC + 4 * threadIdx.x) = v;
-    }
+    load_code_rows<NRR>(XC, a.code, row0 / a.code_rep, (a.m + a.code_rep - 1) / a.code_rep);
   } else {
     dw1.preload(PK ? d.pf1 : d.w1 + ADIM, 260, d.b1, d.w1, ADIM);
     for (int idx = threadIdx.x; idx < R * 64; idx += kThreads) {
@@ -1038,9 +1067,10 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseB
   __syncthreads();
   NDP_STAMP(1);
   if (DD) {
-    code_row_dot<64>(d.pf1, XC, XC + 256);
+    code_rows_dot<64, NRR>(d.pf1, XC, XC + NRR * 260);
     __syncthreads();
-    fc1_from_code_row<64, ACT_LRELU>(XC + 256, d.b1, d.w1, 260, ADIM, XT, B2, 68);       // D.h1 -> B2
+    fc1_from_code_rows<64, ACT_LRELU, NRR>(XC + NRR * 260, d.b1, d.w1, 260, ADIM, XT, B2, 68,
+                                           (int)(row0 % a.code_rep), a.code_rep);        // D.h1 -> B2
   } else {
     dw2.bind(PK ? d.pf2 : d.w2, 64, d.b2, nullptr, 0);
     layer_fwd_run<1, 256, 64, ACT_LRELU, 4, PK>(dw1, XC, 260, B2, 68, XT, TAILLD, dw2);   // D.h1 -> B2
