@@ -842,37 +842,51 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 1 : 3)) void k_phase_a(PhaseA
     // ---------------- G forward
     FwdW<256, 128, 2, PK, RG> gw1;
     FwdW<128, 64, 4, PK, RG> gw2;
-    if (DD) gw2.preload(PK ? g.pf2 : g.w2, 128, g.b2, nullptr, 0);
-    else gw1.preload(PK ? g.pf1 : g.w1, g.ld1, g.b1, g.w1 + CODE, g.nz);
-    const f32x4 w5r = *reinterpret_cast<const f32x4*>(g.w5 + 4 * threadIdx.x);
-    const float b5r = g.b5[threadIdx.x & 3], w4r = d.w4[threadIdx.x], b4r = d.b4[0];
-    NDP_STAMP(24);
+    // The input tile's loads go out BEFORE the weight ring's: loads return in order, so behind the ring's 24 fragments
+    // per lane (1.4 us to issue at kernel start, stamps) the tile's LDS writes waited for all of them.
+    f32x4 ct[R * 64 / kThreads];                          // the code tile, 4 float4 per thread
     if (DD) {                                            // the tile's distinct code rows -> XC rows 0 .. NR-1
       load_code_rows<NRR>(XC, a.code, (int64_t)((uint32_t)row0 / (uint32_t)a.code_rep), a.flat);
     } else {
-      for (int idx = threadIdx.x; idx < R * 64; idx += kThreads) {
+#pragma unroll
+      for (int u = 0; u < R * 64 / kThreads; ++u) {
+        const int idx = threadIdx.x + u * kThreads;
         const int i = idx >> 6, k = 4 * (idx & 63);
         const int64_t row = row0 + i;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < a.m) v = *reinterpret_cast<const f32x4*>(a.code + (size_t)((uint32_t)row / (uint32_t)a.code_rep) * CODE + k);
-        *reinterpret_cast<f32x4*>(XC + i * 260 + k) = v;
+        const bool ok = row < a.m;                       // unconditional load from a valid row, zeroed by a select
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.code + (size_t)((uint32_t)(ok ? row : 0) / (uint32_t)a.code_rep) * CODE + k);
+        ct[u] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const f32x4 w5r = *reinterpret_cast<const f32x4*>(g.w5 + 4 * threadIdx.x);
+    const float b5r = g.b5[threadIdx.x & 3], w4r = d.w4[threadIdx.x], b4r = d.b4[0];
+    float nv = 0.f;                                       // the noise tile: R x TAILLD = one element per thread
+    {
+      static_assert(R * TAILLD == kThreads, "one noise element per thread");
+      const int i = threadIdx.x / TAILLD, t = threadIdx.x % TAILLD;
+      const int64_t row = row0 + i;
+      if (row < a.m && t < g.nz) {
+        if (a.noise_out != nullptr) {
+          nv = philox_uniform((uint64_t)(row * g.nz + t), a.noise_seed, (uint32_t)*a.noise_step);
+          a.noise_out[row * g.nz + t] = nv;
+        } else {
+          nv = a.noise[row * g.nz + t];
+        }
+      }
+    }
+    pin_vmem();
+    if (DD) gw2.preload(PK ? g.pf2 : g.w2, 128, g.b2, nullptr, 0);
+    else gw1.preload(PK ? g.pf1 : g.w1, g.ld1, g.b1, g.w1 + CODE, g.nz);
+    NDP_STAMP(24);
+    if (!DD) {
+#pragma unroll
+      for (int u = 0; u < R * 64 / kThreads; ++u) {
+        const int idx = threadIdx.x + u * kThreads;
+        *reinterpret_cast<f32x4*>(XC + (idx >> 6) * 260 + 4 * (idx & 63)) = ct[u];
       }
     }
     NDP_STAMP(25);
-    for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {
-      const int i = idx / TAILLD, t = idx % TAILLD;
-      const int64_t row = row0 + i;
-      float v = 0.f;
-      if (row < a.m && t < g.nz) {
-        if (a.noise_out != nullptr) {
-          v = philox_uniform((uint64_t)(row * g.nz + t), a.noise_seed, (uint32_t)*a.noise_step);
-          a.noise_out[row * g.nz + t] = v;
-        } else {
-          v = a.noise[row * g.nz + t];
-        }
-      }
-      XT[idx] = v;
-    }
+    XT[threadIdx.x] = nv;
     *reinterpret_cast<f32x4*>(W5S + 4 * threadIdx.x) = w5r;
     if (threadIdx.x < 4) W5S[1024 + threadIdx.x] = b5r;
     W4S[threadIdx.x] = w4r;
@@ -1023,38 +1037,50 @@ __global__ __launch_bounds__(kThreads, (RG >= 96 ? 2 : 3)) void k_phase_b(PhaseB
 
   FwdW<256, 64, 4, PK, RG> dw1;
   FwdW<64, 128, 4, PK, RG> dw2;
-  if (DD) {                                              // the tile's distinct code rows (see code_rows_dot) -> XC rows 0 .. NR-1
-    dw2.preload(PK ? d.pf2 : d.w2, 64, d.b2, nullptr, 0);
-    load_code_rows<NRR>(XC, a.code, row0 / a.code_rep, (a.m + a.code_rep - 1) / a.code_rep);
-  } else {
-    dw1.preload(PK ? d.pf1 : d.w1 + ADIM, 260, d.b1, d.w1, ADIM);
-    for (int idx = threadIdx.x; idx < R * 64; idx += kThreads) {
-      const int i = idx >> 6, k = 4 * (idx & 63);
-      const int64_t row = row0 + i;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < a.m) v = *reinterpret_cast<const f32x4*>(a.code + (row / a.code_rep) * CODE + k);
-      *reinterpret_cast<f32x4*>(XC + i * 260 + k) = v;
+  // The input tile's and the small weights' loads go out BEFORE the weight ring's (see k_phase_a).
+  f32x4 ct[R * 64 / kThreads];
+  float av = 0.f;                                        // the action tile: one element per thread
+  {
+    if (DD) {                                            // the tile's distinct code rows (see code_rows_dot) -> XC rows 0 .. NR-1
+      load_code_rows<NRR>(XC, a.code, row0 / a.code_rep, (a.m + a.code_rep - 1) / a.code_rep);
+    } else {
+#pragma unroll
+      for (int u = 0; u < R * 64 / kThreads; ++u) {
+        const int idx = threadIdx.x + u * kThreads;
+        const int i = idx >> 6, k = 4 * (idx & 63);
+        const int64_t row = row0 + i;
+        const bool ok = row < a.m;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.code + ((ok ? row : 0) / a.code_rep) * CODE + k);
+        ct[u] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const int i = threadIdx.x / TAILLD, t = threadIdx.x % TAILLD;
+    const int64_t row = row0 + i;
+    if (row < a.m && t < ADIM) av = a.action_hat[row * ADIM + t];
+  }
+  const float w1a = d.w1[(threadIdx.x >> 2) * 260 + (threadIdx.x & 3)], w4r = d.w4[threadIdx.x], b4r = d.b4[0];
+  const f32x4 w5r = *reinterpret_cast<const f32x4*>(g.w5 + 4 * threadIdx.x);
+  pin_vmem();
+  if (DD) dw2.preload(PK ? d.pf2 : d.w2, 64, d.b2, nullptr, 0);
+  else dw1.preload(PK ? d.pf1 : d.w1 + ADIM, 260, d.b1, d.w1, ADIM);
+  if (!DD) {
+#pragma unroll
+    for (int u = 0; u < R * 64 / kThreads; ++u) {
+      const int idx = threadIdx.x + u * kThreads;
+      *reinterpret_cast<f32x4*>(XC + (idx >> 6) * 260 + 4 * (idx & 63)) = ct[u];
     }
   }
-  for (int idx = threadIdx.x; idx < R * TAILLD; idx += kThreads) {
-    const int i = idx / TAILLD, t = idx % TAILLD;
-    const int64_t row = row0 + i;
-    XT[idx] = (row < a.m && t < ADIM) ? a.action_hat[row * ADIM + t] : 0.f;
-  }
+  XT[threadIdx.x] = av;
   // G's saved activations: PRE keeps them in registers until D'.fc1 is done (their loads are issued now, behind
   // the input tile, and nothing waits for them here)
   TileRegs<1, 128> t1;
   TileRegs<1, 256> t4;
   TileRegs<1, 128> t3;
   TileRegs<1, 64> t2;
-  {
-    const float w1a = d.w1[(threadIdx.x >> 2) * 260 + (threadIdx.x & 3)], w4r = d.w4[threadIdx.x], b4r = d.b4[0];
-    const f32x4 w5r = *reinterpret_cast<const f32x4*>(g.w5 + 4 * threadIdx.x);
-    W1A[threadIdx.x] = w1a;
-    W4S[threadIdx.x] = w4r;
-    if (threadIdx.x == 0) W4S[256] = b4r;
-    *reinterpret_cast<f32x4*>(W5S + 4 * threadIdx.x) = w5r;
-  }
+  W1A[threadIdx.x] = w1a;
+  W4S[threadIdx.x] = w4r;
+  if (threadIdx.x == 0) W4S[256] = b4r;
+  *reinterpret_cast<f32x4*>(W5S + 4 * threadIdx.x) = w5r;
   if (PRE) {
     t1.load(a.gh1 + row0 * 128, 128);
     t4.load(a.gh4 + row0 * 256, 256);
