@@ -1,6 +1,2 @@
-mkdir -p gpurun_out/fm
 export TMPDIR=/tmp
-timeout -k 10 900 python -m pytest tests/test_gpu_forward_model.py -m gpu -q > gpurun_out/fm/t11.log 2>&1; echo "pytest rc=$?"; grep -n "^E   \|^FAILED\|passed\|failed\|Error" gpurun_out/fm/t11.log | head -20
-N=8 python scripts/probe/fm_time.py 2>&1 | grep "ms/step, \|colstats\|bn_"
-N=32 STEPS=10 python scripts/probe/fm_time.py 2>&1 | grep "ms/step, \|colstats\|bn_"
-N=64 STEPS=6 python scripts/probe/fm_time.py 2>&1 | grep "ms/step, "
+GRAPH=1 N=8 timeout -k 10 300 python scripts/probe/fm_time.py 2>&1 | grep "ms/step\|rror\|loss"
