@@ -634,7 +634,9 @@ def main():
                     return out_
                 extra("headline_through_rccl", rccl_headline)
         else:
-            extra("h2d_per_launch", lambda: h2d_point(b, batch, k, min(args.steps, 2000), spl if spl > 1 else 16))
+            # 64 steps per upload: every launch costs ~250-340 us beyond its graph (upload not fully hidden, event wait
+            # ahead of the replay), whatever its size -- measured 10,630 / 10,770 / 11,940 steps/s at 16 / 32 / 64
+            extra("h2d_per_launch", lambda: h2d_point(b, batch, k, max(min(args.steps, 2560), 640), 64))
             extra("config4", lambda: config4_point(b, 200))
             extra("large_m", lambda: {"config5_shard_b128_k32": large_m_point(b, 128, 32, 60),
                                       "b1024_k6": large_m_point(b, 1024, 6, 60)})
