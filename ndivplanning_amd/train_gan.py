@@ -20,7 +20,7 @@ What differs from the reference, on purpose:
 
 Extra YAML keys (all optional): `train_data_path: synthetic:<N>[:codes|images]` for seeded
 synthetic trajectories, `training.gan.noise_source`, `training.gan.use_graph`,
-`training.gan.steps_per_launch` (iterations per HIP-graph launch, default 4; the batches of one
+`training.gan.steps_per_launch` (iterations per HIP-graph launch, default 16; the batches of one
 launch are staged into separate input slots, the arithmetic is unchanged),
 `training.gan.cache_codes` (default true: encode every trajectory once, the encoder being frozen).
 In data-parallel runs each rank caches only the trajectories of its own shard positions, so the
@@ -143,7 +143,7 @@ def train(config):
                        "(the reference fails at train_gan.py:199 for such a file)")
     noise_source = _get(g, "noise_source", "device")
     use_graph = bool(_get(g, "use_graph", True))
-    steps_per_launch = int(_get(g, "steps_per_launch", 4))
+    steps_per_launch = int(_get(g, "steps_per_launch", 16))
     cache_codes = bool(_get(g, "cache_codes", True))
 
     rank, world, local_rank = dp.env_world()

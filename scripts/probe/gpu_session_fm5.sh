@@ -1,2 +1,3 @@
 export TMPDIR=/tmp
-GRAPH=1 N=8 timeout -k 10 300 python scripts/probe/fm_time.py 2>&1 | grep "ms/step\|rror\|loss"
+mkdir -p gpurun_out/fm
+timeout -k 10 900 python -m pytest tests/test_gpu_train_gan.py -m gpu -q > gpurun_out/fm/t_tg.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/fm/t_tg.log
