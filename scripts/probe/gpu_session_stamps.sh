@@ -1,4 +1,3 @@
-mkdir -p gpurun_out/fm
 export TMPDIR=/tmp
-WHICH=pa B=64 K=6 WARM=3 timeout -k 10 300 python scripts/diag_stamps.py > gpurun_out/fm/stamps_pa.log 2>&1; echo rc=$?; tail -22 gpurun_out/fm/stamps_pa.log
-WHICH=pb B=64 K=6 WARM=3 timeout -k 10 300 python scripts/diag_stamps.py > gpurun_out/fm/stamps_pb.log 2>&1; echo rc=$?; tail -16 gpurun_out/fm/stamps_pb.log
+WHICH=wa B=64 K=6 WARM=3 CH=8 timeout -k 10 300 python scripts/diag_stamps.py 2>&1 | grep -v "warning\|offsetof\|\^\|amdgpu.ids" | tail -26
+WHICH=wb B=64 K=6 WARM=3 timeout -k 10 300 python scripts/diag_stamps.py 2>&1 | grep -v "warning\|offsetof\|\^\|amdgpu.ids" | tail -7
