@@ -1,6 +1,3 @@
 export TMPDIR=/tmp
-for lib in libndp_hip.so libndp_pf10.so libndp_pf14.so libndp_hip.so libndp_pf10.so; do
-echo $lib
-NDP_LIB_PATH=$GRAFT_REPO_ROOT/ndivplanning_amd/lib/$lib NDP_FM_SIDE_STREAM=0 N=8 python scripts/probe/fm_time.py 2>&1 | grep "ms/step, \|wgrad\[deconv3\]\|wgrad\[deconv6\]"
-NDP_LIB_PATH=$GRAFT_REPO_ROOT/ndivplanning_amd/lib/$lib NDP_FM_SIDE_STREAM=0 N=32 STEPS=10 python scripts/probe/fm_time.py 2>&1 | grep "ms/step, \|wgrad\[deconv3\]\|wgrad\[deconv6\]"
-done
+mkdir -p gpurun_out/fm
+timeout -k 10 900 python -m pytest tests/test_gpu_forward_model.py -m gpu -q -k "cli_entry" > gpurun_out/fm/t13.log 2>&1; echo "pytest rc=$?"; grep -n "^E   \|^FAILED\|passed\|failed\|Error" gpurun_out/fm/t13.log | head

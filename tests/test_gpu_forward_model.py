@@ -422,3 +422,34 @@ def test_the_reference_loop_unchanged_module_forward_loss_backward_torch_adam():
     from ndivplanning_amd import _capi
     with pytest.raises(_capi.NdpError):
         r1.sum().backward()
+
+
+def test_cli_entry_in_a_fresh_interpreter_pickles_the_reference_class_path(tmp_path):
+    """`python train_forward_model.py --config-file ...` (the reference's command line) in a new interpreter: the saved
+    whole-module checkpoint must record `models.forward_encoder.ForwardAutoencoder` (what control_evaluation.py:177-180
+    unpickles), not the package-internal path, and load back into the mirror on the kernels' path."""
+    import subprocess
+    import sys
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    save = tmp_path / "fm"
+    save.mkdir()
+    cfg = {"random_seed": 0, "train_data_path": "synthetic:2:images", "gpu_id": 0, "trajectory_length": 2,
+           "forward_save_path": str(save),
+           "training": {"forward": {"num_epochs": 1, "learning_rate": LR, "report_feq": 10, "batch_size": 2,
+                                    "epochs_per_stage": 1, "step_lr_gamma": 0.1}}}
+    with open(tmp_path / "cfg.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    res = subprocess.run([sys.executable, os.path.join(root, "train_forward_model.py"), "--config-file", str(tmp_path / "cfg.yaml"),
+                          "--forward-save-path", str(save)], cwd=root, env=dict(os.environ, PYTHONPATH=root),
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:]
+    path = save / "forward_autoencoder_0.pt"
+    blob = open(path, "rb").read()
+    assert b"models.forward_encoder" in blob and b"ndivplanning_amd.models" not in blob
+    import models.forward_encoder as shim
+    model = torch.load(str(path), weights_only=False).to(DEV).eval()               # our own file
+    assert isinstance(model, shim.ForwardAutoencoder)
+    frames, actions = _inputs(50, 1)
+    pred = model(frames[:, 0].to(DEV), actions[:, 0].to(DEV))
+    assert pred.shape == (1, 3, 128, 128) and bool(torch.isfinite(pred).all())
