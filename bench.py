@@ -34,7 +34,8 @@ Rank 0 prints one JSON line (contract in the task statement) with extra objects:
   forward_model    SURVEY.md section 8 row f4: one iteration of train_forward_model.py (U-Net forward, MSE,
                backward, Adam) at batch 8 and 32, with its kernel-time shares and the oracle timed on the CPU (N = 1);
   strong_config3, config5_shard   (N > 1) global batch 256 split over the ranks, and the config-5 shard
-               per rank, with the gradient exchange that ran and both exchanges timed.
+               per rank, with the gradient exchange that ran and both exchanges timed;
+  forward_model_dp   (N > 1) the forward-model iteration at 8 images per rank with its gradient all-reduce.
 """
 import argparse
 import json
@@ -633,6 +634,43 @@ def main():
                     del t_
                     return out_
                 extra("headline_through_rccl", rccl_headline)
+
+            # the forward (next-frame) model trained data-parallel: 8 images per rank, the 133 MB flat gradient averaged by
+            # one all-reduce between backward and Adam (train_forward_model.py mirror; not overlapped with the backward)
+            def forward_model_dp():
+                from ndivplanning_amd.forward_trainer import ForwardModelTrainer
+                from ndivplanning_amd.models import forward_encoder as FE
+                n_ = 8
+                torch.manual_seed(0)
+                model = FE.ForwardAutoencoder()
+                model.decoder.weight_init(0.0, 0.02)
+                model.encoder.weight_init(0.0, 0.02)
+                t_ = ForwardModelTrainer(model.to(dev).train(), batch=n_, reduce_fn=b.dp.mean_all_reduce(world))
+                gen = torch.Generator().manual_seed(100 + rank)
+                cur, fut = ((torch.rand(n_, 3, 128, 128, generator=gen) * 2 - 1).to(dev) for _ in range(2))
+                act = (torch.rand(n_, 4, generator=gen) * 2 - 1).to(dev)
+                for _ in range(3):
+                    t_.step(cur, fut, act)
+                steps_ = 20
+                b.barrier()
+                t0 = time.perf_counter()
+                for _ in range(steps_):
+                    t_.step(cur, fut, act)
+                b.barrier()
+                sec_ = b.max_over_ranks(time.perf_counter() - t0)
+                ref_ = t_.params.clone()
+                dist.broadcast(ref_, src=0)
+                same = bool(torch.equal(ref_, t_.params))
+                flags = torch.tensor([1.0 if same else 0.0], device=dev)
+                dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+                out_ = {"workload": "train_forward_model.py iteration, 8 images per rank, mean all-reduce of the flat gradient "
+                                    "(%.0f MB) between backward and Adam" % (t_.grad.numel() * 4 / 1e6),
+                        "ms_per_step": round(1e3 * sec_ / steps_, 4), "global_images_per_sec": round(n_ * world * steps_ / sec_, 1),
+                        "replicas_bit_identical": bool(flags.item() == 1.0), "scaling": "weak"}
+                del t_, model
+                torch.cuda.empty_cache()
+                return out_
+            extra("forward_model_dp", forward_model_dp)
         else:
             # 64 steps per upload: every launch costs ~250-340 us beyond its graph (upload not fully hidden, event wait
             # ahead of the replay), whatever its size -- measured 10,630 / 10,770 / 11,940 steps/s at 16 / 32 / 64
