@@ -510,8 +510,109 @@ def h2d_point(b, batch, k, steps, spl):
     return out
 
 
+def child_rank_env(base_env, rank, world, port):
+    """Environment of child rank `rank` of a self-launched N-rank run: the variables torch.distributed.run would set
+    (one process per GPU, rendezvous on the loopback address -- the container hostname may not resolve)."""
+    env = dict(base_env)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "NDP_BENCH_CHILD": "1",
+                "HSA_ENABLE_IPC_MODE_LEGACY": base_env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return env
+
+
+def child_rank_argv(argv):
+    """Command line of one child rank: this interpreter, this file, the parent's own arguments unchanged."""
+    return [sys.executable, os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a torch.distributed.run environment: this process never touches a GPU; it
+    starts N fresh rank processes (never an exec of a process that has initialised the runtime), relays rank 0's one
+    JSON line on stdout, forwards every rank's stderr, enforces a wall-clock limit, and exits non-zero with the
+    failing rank's stderr tail when a rank fails."""
+    import socket
+    import subprocess
+    import tempfile
+    import threading
+    world = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    limit = float(os.environ.get("NDP_BENCH_LAUNCH_TIMEOUT_S", "1500"))
+    tails = [[] for _ in range(world)]
+    procs, threads = [], []
+    rank0_out = tempfile.TemporaryFile(mode="w+")
+
+    def pump(rank, stream):
+        for line in stream:
+            tails[rank].append(line)
+            del tails[rank][:-40]
+            sys.stderr.write(line if rank == 0 else "[rank %d] %s" % (rank, line))
+            sys.stderr.flush()
+
+    for rank in range(world):
+        p = subprocess.Popen(child_rank_argv(argv), env=child_rank_env(os.environ, rank, world, port), cwd=ROOT,
+                             stdin=subprocess.DEVNULL, stdout=rank0_out if rank == 0 else subprocess.DEVNULL,
+                             stderr=subprocess.PIPE, text=True, start_new_session=True)
+        procs.append(p)
+        t = threading.Thread(target=pump, args=(rank, p.stderr), daemon=True)
+        t.start()
+        threads.append(t)
+
+    def stop_all():
+        for p in procs:                      # exactly the processes started above (each its own session / group)
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, 15)
+                except OSError:
+                    pass
+        t_end = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, 9)
+                except OSError:
+                    pass
+
+    t0, failed = time.time(), None
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed = "rank %d exited with code %d" % bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() - t0 > limit:
+                failed = "wall-clock limit of %.0f s reached" % limit
+                break
+            time.sleep(0.05)
+    finally:
+        if failed:
+            stop_all()
+    for t in threads:
+        t.join(timeout=5)
+    rank0_out.seek(0)
+    lines = [ln for ln in rank0_out.read().splitlines() if ln.strip()]
+    json_lines = [ln for ln in lines if ln.lstrip().startswith("{")]
+    if failed is None and not json_lines:
+        failed = "rank 0 printed no JSON line"
+    if failed:
+        r = next((r for r, p in enumerate(procs) if p.returncode not in (None, 0)), 0)
+        sys.stderr.write("[bench] %d-rank run failed: %s\n---- stderr tail of rank %d ----\n%s" % (world, failed, r, "".join(tails[r])))
+        sys.exit(1)
+    print(json_lines[-1], flush=True)
+    sys.exit(0)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args, sys.argv[1:])          # never returns; no GPU call has happened in this process
     b = Bench(args)
     world, rank, dev, dist, O = b.world, b.rank, b.dev, b.dist, b.O
     batch, k = args.batch, args.num_sample
@@ -555,13 +656,8 @@ def main():
             tr = b.make_trainer(batch, k, flat * world, spl, None, b.reduce_fn, use_graph=graph_ok)
             b.fill_slots(tr, batch, k)
     def replicas_in_lockstep(t_):
-        # the replicas must have stayed bit-identical: compare a checksum of the parameter bits
-        bits = torch.cat([t_.g_flat.detach(), t_.d_flat.detach()]).view(torch.int32).to(torch.int64)
-        mine = torch.stack([bits.sum(), (bits * torch.arange(1, bits.numel() + 1, device=dev)).sum()])
-        lo_, hi_ = mine.clone(), mine.clone()
-        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
-        return bool(torch.equal(lo_, hi_))
+        # the replicas must have stayed bit-identical: compare checksums of the parameter bits
+        return b.dp.replicas_bit_identical([t_.g_flat, t_.d_flat])
 
     p2p_note = None
     while True:

@@ -120,6 +120,37 @@ def reduce_loss_shares(shares, device=None):
     return t.tolist()
 
 
+def replicas_bit_identical(tensors, group=None):
+    """True on EVERY rank iff the given (parameter) tensors hold the same BITS on all ranks: two int64 checksums of the
+    bit patterns (plain sum, position-weighted sum), MIN- and MAX-reduced.  Data-parallel replicas apply the same Adam
+    update to the same summed gradient, so they must stay bit-identical; a gradient exchange that delivered a stale or
+    torn sum to one rank shows up here.  Collective (two small all-reduces); synchronises."""
+    bits = torch.cat([t.detach().reshape(-1) for t in tensors]).contiguous().view(torch.int32).to(torch.int64)
+    weights = torch.arange(1, bits.numel() + 1, device=bits.device, dtype=torch.int64)
+    mine = torch.stack([bits.sum(), (bits * weights).sum()])
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return True
+    if dist.get_backend(group) != "nccl":
+        mine = mine.cpu()
+    lo, hi = mine.clone(), mine.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    return bool(torch.equal(lo, hi))
+
+
+class ReplicaDivergence(RuntimeError):
+    """Data-parallel replicas no longer hold identical parameters: the gradient exchange named in the message
+    delivered different sums to different ranks."""
+
+
+def assert_replicas_identical(tensors, exchange, where, group=None):
+    """Raise ReplicaDivergence on every rank (the comparison is collective, so all ranks see the same verdict)."""
+    if not replicas_bit_identical(tensors, group):
+        raise ReplicaDivergence(
+            "data-parallel replicas diverged (%s): the '%s' gradient exchange gave the ranks different sums; rerun with "
+            "NDP_DP_EXCHANGE=rccl to use the collective" % (where, exchange))
+
+
 class P2PExchange:
     """The in-kernel gradient exchange of include/ndp.h ("peer-to-peer gradient exchange"): one
     uncached region per rank, mapped into every peer with hipIpc; the step's slab-reduce kernels

@@ -208,6 +208,18 @@ def train(config):
         action_cache = torch.zeros(len(dataset), seq_length, 4, device=device)
         cached = torch.zeros(len(dataset), dtype=torch.bool)
     history = []
+    # Replicas apply the same Adam update to the same summed gradients, so their parameters must stay bit-identical.
+    # The in-kernel exchange has its own time-out word, but a sum that arrived WRONG (a flag overtaking its data on a
+    # transport it has not met) would train on silently: compare parameter checksums across ranks after the first
+    # launch and at the end of every epoch (two 16-byte all-reduces); a mismatch raises on every rank.
+    lockstep = {"checked_first_launch": world == 1}
+
+    def check_lockstep(where):
+        if world > 1:
+            if p2p is not None:
+                p2p.check()                  # a timed-out wait is an error, not a silent wrong sum
+            dp.assert_replicas_identical([trainer.g_flat, trainer.d_flat], exchange, where)
+
     for epoch in range(num_epochs):
         discriminator.train()
         decoder.train()
@@ -223,6 +235,9 @@ def train(config):
                 for c_, a_, n_ in pending:
                     trainer.step(c_, a_, n_)
             del pending[:]
+            if not lockstep["checked_first_launch"]:
+                lockstep["checked_first_launch"] = True
+                check_lockstep("after the first launch")
 
         all_cached = cached is not None and bool(cached.all())
         loader = None if all_cached else iter(data.DataLoader(dataset, batch_sampler=[b.tolist() for b in batches]))
@@ -257,8 +272,7 @@ def train(config):
             if len(pending) == group:
                 flush()
         flush()
-        if p2p is not None:
-            p2p.check()                      # a timed-out wait is an error, not a silent wrong sum
+        check_lockstep("end of epoch %d" % epoch)
         sums = dp.reduce_loss_shares(trainer.pop_loss_sums(), device=device)
         d_avg, g_avg, div_avg = (v / n_batches for v in sums)                   # train_gan.py:209-211
         history.append((d_avg, g_avg, div_avg))

@@ -133,3 +133,40 @@ def test_mean_all_reduce_of_the_forward_model_recipe(tmp_path):
     want = (torch.arange(6, dtype=torch.float32) * 1 + 0 + torch.arange(6, dtype=torch.float32) * 2 + 4) / 2
     assert torch.equal(a["grad"], want) and torch.equal(b["grad"], want)
     assert a["bounds"] == (0, 4) and b["bounds"] == (4, 8)
+
+
+def _lockstep_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from ndivplanning_amd import dp
+    dp.init_process_group(None)
+    g, d = torch.linspace(-1, 1, 83780), torch.linspace(0, 3, 58305)
+    same = dp.replicas_bit_identical([g, d])
+    # one rank's replica differs in the LAST bit of one parameter: a sum that arrived wrong once
+    if rank == 1:
+        d.view(torch.int32)[12345] ^= 1
+    differ = dp.replicas_bit_identical([g, d])
+    raised = None
+    try:
+        dp.assert_replicas_identical([g, d], "p2p", "end of epoch 0")
+    except dp.ReplicaDivergence as exc:
+        raised = str(exc)
+    # two values swapped on one rank: the plain sum of the bits cannot see it, the position-weighted one must
+    if rank == 1:
+        d.view(torch.int32)[12345] ^= 1
+        g[[5, 9]] = g[[9, 5]]
+    swapped = dp.replicas_bit_identical([g, d])
+    torch.save({"same": same, "differ": differ, "raised": raised, "swapped": swapped}, os.path.join(out_dir, "ls%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_replica_checksums_catch_a_one_bit_divergence_on_every_rank(tmp_path):
+    """What train_gan runs after the first launch and once per epoch of a data-parallel run (and bench.py after timing):
+    identical replicas pass; one flipped bit or two swapped values on one rank fail on BOTH ranks, and the error names
+    the exchange."""
+    mp.spawn(_lockstep_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        res = torch.load(os.path.join(str(tmp_path), "ls%d.pt" % r))
+        assert res["same"] is True and res["differ"] is False and res["swapped"] is False
+        assert res["raised"] is not None and "'p2p'" in res["raised"] and "end of epoch 0" in res["raised"]
