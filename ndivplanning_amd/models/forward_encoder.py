@@ -37,8 +37,11 @@ BN_NAMES = ("encoder.conv1_bn", "encoder.conv2_bn", "encoder.conv3_bn", "decoder
 
 def normal_init(m, mean, std):
     if isinstance(m, (nn.ConvTranspose2d, nn.Conv2d)):
-        m.weight.data.normal_(mean, std)
-        m.bias.data.zero_()
+        # the reference writes through `.data` (forward_encoder.py:13-16); the same draws through no_grad bump the
+        # tensors' version counters, which the packed-parameter cache of ForwardAutoencoder is keyed on
+        with torch.no_grad():
+            m.weight.normal_(mean, std)
+            m.bias.zero_()
 
 
 class Encoder(nn.Module):
@@ -237,7 +240,13 @@ class ForwardAutoencoder(nn.Module):
         return resid if self.training else state_cur + resid
 
     def _versions(self):
-        return tuple(t._version for t in list(self.parameters()) + list(self.buffers()))
+        # (storage address, version) per tensor: an in-place write through torch bumps the version, a re-assigned or
+        # moved parameter changes the address.  Writes through `.data` bump nothing -- call invalidate_cache() after one.
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+
+    def invalidate_cache(self):
+        """Drop the packed parameter copies: the next forward re-reads the module's tensors."""
+        self.__dict__.pop("_ndp_cache", None)
 
     def _forward_hip(self, state_cur, actions):
         lib = _capi.load()

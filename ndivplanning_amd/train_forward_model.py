@@ -53,7 +53,24 @@ def bind_reference_class_paths():
     return missing
 
 
+def _require(config, dotted):
+    """The value at `a.b.c`, or a KeyError that names the key: a missing key reads as an empty map (DotMap's behaviour,
+    which the reference relies on elsewhere), and float() / int() of that is a TypeError about the wrong thing."""
+    node = config
+    for part in dotted.split("."):
+        node = node.get(part, None) if isinstance(node, dict) else None
+        if node is None:
+            break
+    if node is None or (isinstance(node, dict) and not node):
+        raise KeyError("%s is missing from the config (the reference's config/default.yaml has it)" % dotted)
+    return node
+
+
 def train(config):
+    for key in ("num_epochs", "learning_rate", "batch_size", "epochs_per_stage"):
+        _require(config, "training.forward." + key)
+    for key in ("random_seed", "train_data_path", "forward_save_path"):
+        _require(config, key)
     f = config.training.forward
     random_seed = int(config.random_seed)
     lr_rate, num_epochs, batch_size = float(f.learning_rate), int(f.num_epochs), int(f.batch_size)

@@ -453,3 +453,29 @@ def test_cli_entry_in_a_fresh_interpreter_pickles_the_reference_class_path(tmp_p
     frames, actions = _inputs(50, 1)
     pred = model(frames[:, 0].to(DEV), actions[:, 0].to(DEV))
     assert pred.shape == (1, 3, 128, 128) and bool(torch.isfinite(pred).all())
+
+
+def test_weight_init_after_a_forward_is_seen_by_the_next_forward():
+    """The reference's `__main__` pattern (forward_encoder.py:117-131): construct, run, then re-initialise.  The module keeps
+    packed copies of its parameters between forwards; weight_init (and any in-place write through torch, or
+    invalidate_cache() after a write through `.data`) must make the next forward read the new weights."""
+    from ndivplanning_amd.models import forward_encoder as FE
+    torch.manual_seed(3)
+    model = FE.ForwardAutoencoder().to(DEV).eval()
+    gen = torch.Generator().manual_seed(9)
+    x = (torch.rand(2, 3, 128, 128, generator=gen) * 2 - 1).to(DEV)
+    a = (torch.rand(2, 4, generator=gen) * 2 - 1).to(DEV)
+    with torch.no_grad():
+        y0 = model(x, a).clone()
+        assert torch.equal(model(x, a), y0)                               # cached packed parameters, same result
+        model.encoder.weight_init(0.0, 0.02)
+        model.decoder.weight_init(0.0, 0.02)
+        y1 = model(x, a).clone()
+        want = FO.forward({k: v.cpu() for k, v in model.state_dict().items()}, x.cpu(), a.cpu(), training=False)
+        assert (y1 - y0).abs().max().item() > 1e-3                        # the new weights were used ...
+        assert (y1.cpu() - want).abs().max().item() <= 5e-5               # ... and give the oracle's output for them
+        model.decoder.conv_refine_2.bias.data.add_(0.25)                  # a write through .data bumps no version counter
+        model.invalidate_cache()
+        y2 = model(x, a)
+        want2 = FO.forward({k: v.cpu() for k, v in model.state_dict().items()}, x.cpu(), a.cpu(), training=False)
+        assert (y2 - y1).abs().max().item() > 1e-2 and (y2.cpu() - want2).abs().max().item() <= 5e-5

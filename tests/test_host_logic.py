@@ -57,10 +57,51 @@ def test_shipped_configs_have_the_reference_keys():
     import yaml
     ref_keys = {"num_epochs", "num_sample", "noise_dim", "learning_rate", "report_feq", "batch_size",
                 "discrim_steps_per_gen", "epochs_per_stage", "pairwise_div_factor"}
+    fwd_keys = {"num_epochs", "learning_rate", "report_feq", "batch_size", "epochs_per_stage", "step_lr_gamma"}
     for name in os.listdir(os.path.join(ROOT, "config")):
         cfg = yaml.safe_load(open(os.path.join(ROOT, "config", name)))
-        assert ref_keys <= set(cfg["training"]["gan"]), name
+        if "gan" in cfg["training"]:
+            assert ref_keys <= set(cfg["training"]["gan"]), name
+        if "forward" in cfg["training"]:
+            assert fwd_keys <= set(cfg["training"]["forward"]), name
+            assert "forward_save_path" in cfg, name
+        assert "gan" in cfg["training"] or "forward" in cfg["training"], name
         assert cfg["trajectory_length"] == 8
+    default = yaml.safe_load(open(os.path.join(ROOT, "config", "default.yaml")))
+    assert {"gan", "forward"} <= set(default["training"])           # the reference's default.yaml has both blocks
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks that the scripts get as far as the GPU check")
+def test_every_shipped_config_parses_up_to_the_gpu_check(tmp_path, monkeypatch):
+    """`python train_gan.py --config-file config/X.yaml` / `python train_forward_model.py --config-file ...`: every key the
+    script reads before it asks for a GPU is present with the right type in every shipped file."""
+    import yaml
+    from ndivplanning_amd import train_forward_model, train_gan
+    from ndivplanning_amd.utils.argparse_util import override_dotmap
+    from ndivplanning_amd.utils.cli_arguments.common_arguments import add_common_arguments
+    from ndivplanning_amd.utils.file import make_paths_absolute
+    monkeypatch.chdir(ROOT)
+    for name in sorted(os.listdir(os.path.join(ROOT, "config"))):
+        raw = yaml.safe_load(open(os.path.join(ROOT, "config", name)))
+        args = add_common_arguments(argparse.ArgumentParser()).parse_args(["--config-file", os.path.join("config", name)])
+        cfg = make_paths_absolute(os.getcwd(), override_dotmap(args, "config_file"))
+        if "gan" in raw["training"]:
+            with pytest.raises(RuntimeError, match="needs a ROCm GPU"):
+                train_gan.train(cfg)
+        if "forward" in raw["training"]:
+            with pytest.raises(RuntimeError, match="needs a ROCm GPU"):
+                train_forward_model.train(cfg)
+
+
+def test_forward_model_script_names_a_missing_key():
+    from ndivplanning_amd import train_forward_model
+    from ndivplanning_amd.utils.file import AttrDict
+    cfg = AttrDict({"random_seed": 0, "train_data_path": "synthetic:8:images", "forward_save_path": "x",
+                    "training": {"forward": {"num_epochs": 1, "batch_size": 8, "epochs_per_stage": 1}}})
+    with pytest.raises(KeyError, match="training.forward.learning_rate"):
+        train_forward_model.train(cfg)
+    with pytest.raises(KeyError, match="training.forward.num_epochs"):
+        train_forward_model.train(AttrDict({"random_seed": 0}))
 
 
 # ------------------------------------------------------------------ data
