@@ -28,14 +28,21 @@ macs = 1.73e9 * 3 * n
 print("batch %d: %.3f ms/step, %.1f steps/s, %.1f images/s, ~%.1f TFLOP/s (fwd+bwd ~ %.1f GMAC)" % (n, dt * 1e3, 1 / dt, n / dt, 2 * macs / dt / 1e12, macs / 1e9))
 print("loss", tr.loss.item())
 from ndivplanning_amd import _capi
+was = _capi.load().ndp_fm_side_stream(0)          # one stream: the per-launch durations do not overlap
 _capi.timing_enable(True)
 for _ in range(3):
     tr.step(cur, fut, act)
 torch.cuda.synchronize()
 timed = _capi.timing_collect()
 _capi.timing_enable(False)
+_capi.load().ndp_fm_side_stream(was)
 tot = sum(v[0] for v in timed.values())
-print("per label (HIP events, 3 steps): total %.3f ms/step" % (tot / 3))
+print("per label (HIP events, 3 steps, one stream): total %.3f ms/step, %d launches/step" % (tot / 3, sum(v[1] for v in timed.values()) // 3))
+groups = {}
+for name, (ms, cnt) in timed.items():
+    g = groups.setdefault(name.split("[")[0], [0.0, 0]); g[0] += ms; g[1] += cnt
+for name, (ms, cnt) in sorted(groups.items(), key=lambda kv: -kv[1][0]):
+    print("  = %-26s %3d launches/step  %8.1f us each  %7.1f us/step %5.1f%%" % (name, cnt // 3, ms / cnt * 1e3, ms / 3 * 1e3, 100 * ms / tot))
 for name, (ms, cnt) in sorted(timed.items(), key=lambda kv: -kv[1][0]):
     print("  %-28s %3d launches/step  %8.1f us each  %7.1f us/step %5.1f%%" % (name, cnt // 3, ms / cnt * 1e3, ms / 3 * 1e3, 100 * ms / tot))
 if os.environ.get("GRAPH"):
