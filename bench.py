@@ -35,7 +35,8 @@ Rank 0 prints one JSON line (contract in the task statement) with extra objects:
                backward, Adam) at batch 8 and 32, with its kernel-time shares and the oracle timed on the CPU (N = 1);
   strong_config3, config5_shard   (N > 1) global batch 256 split over the ranks, and the config-5 shard
                per rank, with the gradient exchange that ran and both exchanges timed;
-  forward_model_dp   (N > 1) the forward-model iteration at 8 images per rank with its gradient all-reduce.
+  forward_model_dp   (N > 1) the forward-model iteration at 8 images per rank with its gradient all-reduce: per bucket,
+               overlapped with the backward pass, and as one collective; exposed_all_reduce_ms for both.
 """
 import argparse
 import json
@@ -731,40 +732,50 @@ def main():
                     return out_
                 extra("headline_through_rccl", rccl_headline)
 
-            # the forward (next-frame) model trained data-parallel: 8 images per rank, the 133 MB flat gradient averaged by
-            # one all-reduce between backward and Adam (train_forward_model.py mirror; not overlapped with the backward)
+            # the forward (next-frame) model trained data-parallel, 8 images per rank: the 133 MB flat gradient averaged
+            # (a) bucket by bucket on a communication stream while the backward pass is still running (the default of the
+            # train_forward_model.py mirror), (b) by ONE all-reduce between backward and Adam; and the same iteration with
+            # no exchange at all, so that the part of the all-reduce that is NOT hidden can be read off
             def forward_model_dp():
                 from ndivplanning_amd.forward_trainer import ForwardModelTrainer
                 from ndivplanning_amd.models import forward_encoder as FE
-                n_ = 8
-                torch.manual_seed(0)
-                model = FE.ForwardAutoencoder()
-                model.decoder.weight_init(0.0, 0.02)
-                model.encoder.weight_init(0.0, 0.02)
-                t_ = ForwardModelTrainer(model.to(dev).train(), batch=n_, reduce_fn=b.dp.mean_all_reduce(world))
+                n_, steps_ = 8, 20
                 gen = torch.Generator().manual_seed(100 + rank)
                 cur, fut = ((torch.rand(n_, 3, 128, 128, generator=gen) * 2 - 1).to(dev) for _ in range(2))
                 act = (torch.rand(n_, 4, generator=gen) * 2 - 1).to(dev)
-                for _ in range(3):
-                    t_.step(cur, fut, act)
-                steps_ = 20
-                b.barrier()
-                t0 = time.perf_counter()
-                for _ in range(steps_):
-                    t_.step(cur, fut, act)
-                b.barrier()
-                sec_ = b.max_over_ranks(time.perf_counter() - t0)
-                ref_ = t_.params.clone()
-                dist.broadcast(ref_, src=0)
-                same = bool(torch.equal(ref_, t_.params))
-                flags = torch.tensor([1.0 if same else 0.0], device=dev)
-                dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+
+                def run(kind):
+                    torch.manual_seed(0)
+                    model = FE.ForwardAutoencoder()
+                    model.decoder.weight_init(0.0, 0.02)
+                    model.encoder.weight_init(0.0, 0.02)
+                    kw = {"single": dict(reduce_fn=b.dp.mean_all_reduce(world)),
+                          "bucketed": dict(bucket_reduce=b.dp.BucketedMeanAllReduce(world)), "none": {}}[kind]
+                    t_ = ForwardModelTrainer(model.to(dev).train(), batch=n_, **kw)
+                    for _ in range(3):
+                        t_.step(cur, fut, act)
+                    b.barrier()
+                    t0 = time.perf_counter()
+                    for _ in range(steps_):
+                        t_.step(cur, fut, act)
+                    b.barrier()
+                    sec_ = b.max_over_ranks(time.perf_counter() - t0)
+                    same = b.dp.replicas_bit_identical([t_.params]) if kind != "none" else None
+                    mb = t_.grad.numel() * 4 / 1e6
+                    del t_, model
+                    torch.cuda.empty_cache()
+                    return 1e3 * sec_ / steps_, same, mb
+                base_ms, _, mb = run("none")
                 out_ = {"workload": "train_forward_model.py iteration, 8 images per rank, mean all-reduce of the flat gradient "
-                                    "(%.0f MB) between backward and Adam" % (t_.grad.numel() * 4 / 1e6),
-                        "ms_per_step": round(1e3 * sec_ / steps_, 4), "global_images_per_sec": round(n_ * world * steps_ / sec_, 1),
-                        "replicas_bit_identical": bool(flags.item() == 1.0), "scaling": "weak"}
-                del t_, model
-                torch.cuda.empty_cache()
+                                    "(%.0f MB)" % mb, "scaling": "weak", "ms_per_step_without_exchange": round(base_ms, 4)}
+                for kind in ("bucketed", "single"):
+                    ms_, same, _ = run(kind)
+                    out_[kind] = {"ms_per_step": round(ms_, 4), "global_images_per_sec": round(n_ * world * 1e3 / ms_, 1),
+                                  "exposed_all_reduce_ms": round(ms_ - base_ms, 4), "replicas_bit_identical": same}
+                out_["replicas_bit_identical"] = bool(out_["bucketed"]["replicas_bit_identical"] and out_["single"]["replicas_bit_identical"])
+                out_["how"] = ("bucketed: 7 ranges of the flat gradient, each all-reduced on a communication stream as soon as the "
+                               "backward pass has completed it (ndp_fm_grad_buckets / ndp_fm_bucket_wait); single: one "
+                               "collective between backward and Adam")
                 return out_
             extra("forward_model_dp", forward_model_dp)
         else:

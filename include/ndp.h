@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NDP_VERSION 132          /* 0.3.2: ndp_fm_* (forward / next-frame model), ndp_fm_backward, ndp_fm_side_stream */
+#define NDP_VERSION 133          /* 0.3.2: ndp_fm_* (forward / next-frame model), ndp_fm_backward, ndp_fm_side_stream */
 
 #define NDP_OK            0
 #define NDP_E_ARG         1      /* bad argument (shape, alignment, null) */
@@ -357,6 +357,15 @@ int ndp_fm_train_grads(const float *params, float *running_stats, const float *s
  * captures, but the HIP graph of it replayed at 3.9 ms against 2.0 ms eager -- and a graph of the single-stream step
  * gains nothing over eager either), returns the previous setting. */
 int ndp_fm_side_stream(int on);
+/* Gradient buckets for a data-parallel driver (the reference trains on one device: train_forward_model.py:62; the
+ * north star asks for the all-reduce of the gradients "overlapped with backward").  ndp_fm_grad_buckets writes the 7
+ * ranges (offset, count: floats of the flat gradient) in the order in which a backward pass completes them -- the weight
+ * gradients come last layer first -- and returns 7.  Every ndp_fm_train_grads / ndp_fm_backward call records one event
+ * per bucket where its last byte is written; ndp_fm_bucket_wait(b, stream) makes `stream` (the caller's communication
+ * stream) wait for bucket b of the most recent such call on the current device, so that its all-reduce runs beside the
+ * rest of the backward pass.  The buckets cover the whole vector exactly once. */
+int ndp_fm_grad_buckets(int64_t *offsets, int64_t *counts, int capacity);
+int ndp_fm_bucket_wait(int bucket, void *stream);
 int ndp_fm_backward(const float *params, const float *d_resid, int64_t n_images, float *grad,
                     float *workspace, void *stream);
 int ndp_fm_apply_adam(float *params, const float *grad, float *exp_avg, float *exp_avg_sq,

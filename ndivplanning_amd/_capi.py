@@ -17,7 +17,7 @@ ACTION_DIM = 4
 MAX_NOISE_DIM = 16
 MAX_SAMPLES = 256
 ROW_PAD = 32
-EXPECTED_VERSION = 132          # NDP_VERSION of include/ndp.h this binding was written against
+EXPECTED_VERSION = 133          # NDP_VERSION of include/ndp.h this binding was written against
 
 _lib = None
 
@@ -109,6 +109,8 @@ SIGNATURES = {
     "ndp_fm_train_grads": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),
     "ndp_fm_side_stream": (c_int, [c_int]),
+    "ndp_fm_grad_buckets": (c_int, [POINTER(c_int64), POINTER(c_int64), c_int]),
+    "ndp_fm_bucket_wait": (c_int, [c_int, c_void_p]),
     "ndp_fm_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "ndp_fm_apply_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                                   c_void_p, c_void_p]),
@@ -208,3 +210,15 @@ def d_param_count():
 
 def pad_rows(m):
     return (int(m) + ROW_PAD - 1) // ROW_PAD * ROW_PAD
+
+
+def fm_grad_buckets():
+    """[(offset, count)]: the ranges of the forward model's flat gradient in completion order (ndp_fm_grad_buckets)."""
+    lib = load()
+    off = (ctypes.c_int64 * 16)()
+    cnt = (ctypes.c_int64 * 16)()
+    n = lib.ndp_fm_grad_buckets(off, cnt, 16)
+    if n <= 0:
+        msg = lib.ndp_last_error()
+        raise NdpError("ndp_fm_grad_buckets failed: %s" % (msg.decode() if msg else "?"))
+    return [(int(off[i]), int(cnt[i])) for i in range(n)]

@@ -99,6 +99,46 @@ def mean_all_reduce(world, group=None):
     return reduce_fn
 
 
+class BucketedMeanAllReduce:
+    """Forward-model gradient exchange overlapped with the backward pass (ForwardModelTrainer(bucket_reduce=...)).
+
+    The library records an event per gradient bucket where the backward pass completes it (ndp_fm_grad_buckets: 7 ranges
+    of the flat vector, last layers first; include/ndp.h).  Called right after ndp_fm_train_grads has ENQUEUED the pass,
+    this makes a communication stream wait for each bucket's event in turn and all-reduces (RCCL) and averages that range
+    there, while the launch stream is still computing the earlier layers' gradients; the launch stream then waits for the
+    communication stream, so what follows (Adam) sees the reduced vector.  Averaging a range elementwise is the same
+    arithmetic whatever the bucketing: with two ranks (one addition per element) the result is bit-identical to
+    mean_all_reduce's single collective; with more, RCCL's summation order per element may differ between message sizes,
+    the replicas still agree with each other bit for bit.
+
+    With a backend that stages CUDA tensors through the host (gloo, the one-GPU rehearsals) each collective blocks the
+    host until its bucket is complete: correct, but not overlapped."""
+
+    def __init__(self, world, group=None):
+        self.world, self.group = int(world), group
+        self.stream = None
+        self.buckets = None
+
+    def __call__(self, flat_grad, device):
+        from . import _capi
+        lib = _capi.load()
+        if self.buckets is None:
+            self.buckets = _capi.fm_grad_buckets()
+            if sum(c for _, c in self.buckets) != flat_grad.numel():
+                raise _capi.NdpError("gradient buckets do not cover the flat gradient")
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device)
+        main = torch.cuda.current_stream(device)
+        scale = 1.0 / self.world
+        with torch.cuda.device(device), torch.cuda.stream(self.stream):
+            for b, (off, cnt) in enumerate(self.buckets):
+                _capi.check(lib.ndp_fm_bucket_wait(b, _capi.stream_ptr(device)), "ndp_fm_bucket_wait")
+                piece = flat_grad[off:off + cnt]
+                dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group)
+                piece.mul_(scale)
+        main.wait_stream(self.stream)
+
+
 def run_step(backend, reduce_fn, discrim_steps=1):
     """One training iteration in data-parallel order.  `backend` provides
     d_grads(first) -> flat D gradient, apply_d(grad), g_grads() -> flat G gradient, apply_g(grad)."""

@@ -9,7 +9,9 @@ The trainer owns the flat parameter vector the kernels read (include/ndp.h: forw
 and the running BatchNorm statistics; `sync_to_module()` writes them back into the `ForwardAutoencoder` (the reference
 saves the whole module: train_forward_model.py:157-163).  `reduce_fn(grad)` -- when given, called between the two
 library calls -- is where a data-parallel driver all-reduces the gradient (SURVEY.md section 8f-4: "same DP recipe";
-the loss is a mean over the local batch, so the driver averages)."""
+the loss is a mean over the local batch, so the driver averages).  `bucket_reduce` (dp.BucketedMeanAllReduce) does the
+same per gradient bucket on a communication stream, each bucket as soon as the backward pass has completed it
+(ndp_fm_grad_buckets / ndp_fm_bucket_wait): the all-reduce runs beside the rest of the backward pass."""
 import torch
 
 from . import _capi
@@ -18,7 +20,7 @@ from .models import forward_encoder as FE
 
 class ForwardModelTrainer:
     def __init__(self, model: FE.ForwardAutoencoder, batch: int, lr: float = 2e-4, betas=(0.5, 0.999), eps: float = 1e-8,
-                 reduce_fn=None, keep_residual: bool = False):
+                 reduce_fn=None, keep_residual: bool = False, bucket_reduce=None):
         self.lib = _capi.load()
         self.model = model
         dev = next(model.parameters()).device
@@ -26,7 +28,9 @@ class ForwardModelTrainer:
             raise _capi.NdpError("ForwardModelTrainer needs the model on a ROCm GPU (got %s); there is no CPU path" % dev)
         self.device, self.batch = dev, int(batch)
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
-        self.reduce_fn = reduce_fn
+        if reduce_fn is not None and bucket_reduce is not None:
+            raise ValueError("give either reduce_fn (one collective) or bucket_reduce (per-bucket, overlapped)")
+        self.reduce_fn, self.bucket_reduce = reduce_fn, bucket_reduce
         f32 = dict(dtype=torch.float32, device=dev)
         self.params, self.stats = FE.pack_module(model, dev)
         self.grad = torch.zeros_like(self.params)
@@ -74,10 +78,16 @@ class ForwardModelTrainer:
     def step(self, state_cur, state_fut, actions):
         """The loop body of train_forward_model.py:98-112 for one frame pair; returns the loss (device scalar)."""
         self.grads(state_cur, state_fut, actions)
-        if self.reduce_fn is not None:
+        if self.bucket_reduce is not None:
+            self.bucket_reduce(self.grad, self.device)
+        elif self.reduce_fn is not None:
             self.reduce_fn(self.grad)
         self.apply()
         return self.loss
+
+    def gradient_buckets(self):
+        """[(offset, count)] of the flat gradient, in the order the backward pass completes them."""
+        return _capi.fm_grad_buckets()
 
     # intermediate maps of the last grads() call (tests, inspection): name -> (workspace tensor index, side, channels kept)
     _MAPS = {"feat1": (1, 64, 128, 64, 128), "up5": (1, 64, 128, 0, 64), "feat2": (2, 32, 256, 128, 256), "up4": (2, 32, 256, 0, 128),

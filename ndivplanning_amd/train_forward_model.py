@@ -111,8 +111,16 @@ def train(config):
         import torch.distributed as dist
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, src=0)
+    # data parallel: the mean of the ranks' gradients, either per gradient bucket on a communication stream while the
+    # backward pass is still running (default) or as ONE collective between backward and Adam
+    # (`training.forward.grad_exchange: single`); two ranks give bit-identical parameters either way
+    exchange = f.get("grad_exchange", None) if hasattr(f, "get") else None
+    exchange = "bucketed" if exchange is None or (isinstance(exchange, dict) and not exchange) else str(exchange)
+    if exchange not in ("bucketed", "single"):
+        raise ValueError("training.forward.grad_exchange must be 'bucketed' or 'single', got %r" % (exchange,))
     trainer = ForwardModelTrainer(model, batch=local_batch, lr=lr_rate, betas=(0.5, 0.999),
-                                  reduce_fn=dp.mean_all_reduce(world) if world > 1 else None)
+                                  reduce_fn=dp.mean_all_reduce(world) if world > 1 and exchange == "single" else None,
+                                  bucket_reduce=dp.BucketedMeanAllReduce(world) if world > 1 and exchange == "bucketed" else None)
 
     history = []
     step = 0

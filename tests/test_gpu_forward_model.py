@@ -378,6 +378,48 @@ def test_two_ranks_on_one_gpu_average_their_gradients(tmp_path):
     for name in ("decoder.deconv2.weight", "encoder.conv5.weight", "decoder.conv_refine_1.weight"):
         diff = (res[0]["named"][name] - state[name].detach()).abs()
         assert float(diff.mean()) <= 0.05 * LR, (name, float(diff.mean()))
+    # ---- that run averaged the gradient bucket by bucket on a communication stream (the default); ONE collective between
+    # backward and Adam (`grad_exchange: single`) must give the same bits: two ranks, one addition per element
+    cfg["training"]["forward"]["grad_exchange"] = "single"
+    single_dir = tmp_path / "single"
+    single_dir.mkdir()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_fm_rank_main, args=(2, port, cfg, str(single_dir)), nprocs=2, join=True)
+    single = torch.load(str(single_dir / "fm_rank0.pt"))
+    assert torch.equal(single["params"], res[0]["params"]) and single["hist"] == res[0]["hist"]
+
+
+def test_gradient_buckets_cover_the_flat_vector_in_completion_order():
+    """ndp_fm_grad_buckets: 7 disjoint ranges that tile the flat gradient; the last layers (whose weight gradients the
+    backward pass finishes first) come first, deconv2 -- half of all parameters -- has a bucket of its own."""
+    from ndivplanning_amd import _capi
+    lib = _capi.load()
+    buckets = _capi.fm_grad_buckets()
+    total = lib.ndp_fm_param_floats()
+    assert len(buckets) == 7 and sum(c for _, c in buckets) == total
+    covered = sorted(buckets)
+    assert covered[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(covered, covered[1:])) and covered[-1][0] + covered[-1][1] == total
+    import ctypes
+    off, dims = ctypes.c_int64(), (ctypes.c_int64 * 6)()
+    _capi.check(lib.ndp_fm_layout(0, 7, ctypes.byref(off), dims), "ndp_fm_layout")      # decoder.deconv2
+    assert buckets[2][0] == off.value and buckets[2][1] == 2048 * 16 * 512 + 512
+    assert buckets[0][0] > buckets[1][0] > buckets[2][0] > buckets[3][0] > buckets[4][0] > buckets[5][0] == 0
+    # a backward pass records the events; waiting for them on a second stream orders that stream behind the pass
+    tr, _ = _hip_trainer(0, 2)
+    frames, actions = _inputs(1, 2)
+    cur, fut, act = (t.contiguous().to(DEV) for t in (frames[:, 0], frames[:, 1], actions[:, 0]))
+    tr.grads(cur, fut, act)
+    side = torch.cuda.Stream(DEV)
+    sums = []
+    with torch.cuda.stream(side):
+        for b, (o, c) in enumerate(buckets):
+            _capi.check(lib.ndp_fm_bucket_wait(b, _capi.stream_ptr(DEV)), "ndp_fm_bucket_wait")
+            sums.append(tr.grad[o:o + c].double().abs().sum())
+    torch.cuda.synchronize(DEV)
+    want = [tr.grad[o:o + c].double().abs().sum().item() for o, c in buckets]
+    assert [s_.item() for s_ in sums] == want and all(w > 0 for w in want)
 
 
 def test_the_reference_loop_unchanged_module_forward_loss_backward_torch_adam():
