@@ -214,6 +214,15 @@ class Bench:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def copy_stream(self):
+        """ONE upload stream for every workload of this process that overlaps host-to-device copies with compute: the GPU
+        runs a handful of hardware queues side by side and time-slices beyond that -- with the graph-upload stream, a second
+        copy stream and the forward model's weight-gradient stream all in use, every kernel of the forward model ran 2-4x
+        slower (4.47 instead of 1.90 ms per iteration; GPU_MAX_HW_QUEUES=2 restored it)."""
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream(self.dev)
+        return self._copy_stream
+
     def make_trainer(self, batch, k, global_flat, spl, p2p, reduce_fn, use_graph=True):
         from ndivplanning_amd.models.gan import Decoder, Discriminator
         from ndivplanning_amd.trainer import GanTrainer
@@ -224,7 +233,8 @@ class Bench:
         if p2p is not None:
             p2p.reset()                # a new trainer counts its exchanges from 1 again: flags must be zero
         return GanTrainer(dec, dis, flat=batch * (TRAJ - 1), num_sample=k, flat_global=global_flat, reduce_fn=reduce_fn,
-                          p2p=p2p, use_graph=use_graph, noise_seed=self.rank, steps_per_launch=spl)
+                          p2p=p2p, use_graph=use_graph, noise_seed=self.rank, steps_per_launch=spl,
+                          copy_stream=self.copy_stream() if self.world == 1 else None)
 
     def fill_slots(self, tr, batch, k, seed0=2000):
         for slot in range(tr.nslots):
@@ -370,6 +380,59 @@ def config4_point(b, steps):
     losses = tr.losses()
     enc_tflops = ENCODER_FLOP_PER_IMAGE * n_img / (enc_ms * 1e-3) / 1e12
     m = batch * (TRAJ - 1) * k
+
+    # ---- the same iteration END TO END, upload included (the reference uploads every batch: train_gan.py:119-124).
+    # Frames leave the loader as decoded bytes [B,8,128,128,3]; they are uploaded as bytes (a quarter of the reference's
+    # float upload) into one of two device buffers by a copy stream while the other buffer's batch is encoded and trained
+    # on; the first convolution normalises them as it gathers (ndp_encoder_forward_u8).
+    gen8 = torch.Generator().manual_seed(6)
+    pool = [torch.randint(0, 256, (n_img, 128, 128, 3), generator=gen8, dtype=torch.uint8).pin_memory() for _ in range(3)]
+    dev_buf = [torch.empty(n_img, 128, 128, 3, dtype=torch.uint8, device=b.dev) for _ in range(2)]
+    host_f32 = torch.empty(n_img, 3, 128, 128).pin_memory()
+    dev_f32 = torch.empty(n_img, 3, 128, 128, device=b.dev)
+    copy_stream = b.copy_stream()
+    main = torch.cuda.current_stream(b.dev)
+
+    def time_copy(dst, src, reps=5):
+        torch.cuda.synchronize(b.dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            dst.copy_(src, non_blocking=True)
+        e1.record()
+        torch.cuda.synchronize(b.dev)
+        return e0.elapsed_time(e1) / reps
+    h2d_u8_ms, h2d_f32_ms = time_copy(dev_buf[0], pool[0]), time_copy(dev_f32, host_f32)
+    del host_f32, dev_f32
+    uploaded = [torch.cuda.Event(), torch.cuda.Event()]
+    consumed = [torch.cuda.Event(), torch.cuda.Event()]
+
+    def upload(i):
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(consumed[i % 2])                    # the batch that last used this buffer is done with it
+            dev_buf[i % 2].copy_(pool[i % 3], non_blocking=True)
+            uploaded[i % 2].record(copy_stream)
+
+    def iteration(i):
+        upload(i + 1)                                                 # next batch's upload runs beside this batch's work
+        main.wait_event(uploaded[i % 2])
+        with torch.no_grad():
+            c128 = enc(dev_buf[i % 2])
+        consumed[i % 2].record(main)
+        tr.step(encode_batch(c128.reshape(batch, TRAJ, 128), None, TRAJ), actions_dev)
+    actions_dev = actions.to(b.dev)
+    consumed[0].record(main)
+    consumed[1].record(main)
+    upload(0)
+    for i in range(3):
+        iteration(i)
+    torch.cuda.synchronize(b.dev)
+    n_it = 12
+    t0 = time.perf_counter()
+    for i in range(3, 3 + n_it):
+        iteration(i)
+    torch.cuda.synchronize(b.dev)
+    e2e_ms = 1e3 * (time.perf_counter() - t0) / n_it
     out = {"workload": "BASELINE configs[3]: image-conditioned step, batch=128 trajectories x 8 frames of 3x128x128, "
                        "num_sample=6; synthetic images, seeded random-init encoder",
            "unique_images": n_img, "rows": m,
@@ -379,11 +442,19 @@ def config4_point(b, steps):
            "step_frac_of_fp32_mfma_peak": round(step_flops(m) / (step_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
            "image_step_ms": round(enc_ms + step_ms, 4),
            "image_steps_per_sec": round(1e3 / (enc_ms + step_ms), 2),
+           "h2d_ms": round(h2d_u8_ms, 4),
+           "h2d_note": "upload of one batch's %d frames from pinned host memory as decoded bytes [n,128,128,3] (%.1f MB); as "
+                       "the reference's float tensors (%.1f MB) it takes %.3f ms" % (n_img, n_img * 49152 / 1e6,
+                                                                                     n_img * 196608 / 1e6, h2d_f32_ms),
+           "image_step_ms_with_upload": round(e2e_ms, 4),
+           "image_steps_per_sec_with_upload": round(1e3 / e2e_ms, 2),
+           "with_upload_how": "every iteration uploads a fresh batch of byte frames (double-buffered, copy stream), encodes "
+                              "it (conv1 normalises while gathering) and runs the fused step: wall clock per iteration",
            "cached_codes_steps_per_sec": round(1e3 / step_ms, 2),
            "flops_as_reference_writes_it": "2 x 896 encoder passes = %.3f TFLOP/step; de-duplicated %.3f TFLOP/step"
                                            % (ENCODER_FLOP_PER_IMAGE * 2 * 896 / 1e12, ENCODER_FLOP_PER_IMAGE * n_img / 1e12),
            "last_losses": {"D": losses[0], "G": losses[1], "ndiv": losses[2]}}
-    del tr, enc, frames
+    del tr, enc, frames, pool, dev_buf
     torch.cuda.empty_cache()
     return out
 
@@ -689,7 +760,11 @@ def main():
     # ---- further workloads (every rank takes part in the N > 1 ones; failures never cost the headline line)
     extras, extra_errors = {}, {}
 
+    only = [x for x in os.environ.get("NDP_BENCH_EXTRAS", "").split(",") if x]     # diagnostics: run just these extras
+
     def extra(name, fn):
+        if only and name not in only:
+            return
         try:
             extras[name] = fn()
         except Exception as exc:                                           # noqa: BLE001

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NDP_VERSION 133          /* 0.3.2: ndp_fm_* (forward / next-frame model), ndp_fm_backward, ndp_fm_side_stream */
+#define NDP_VERSION 134          /* 0.3.2: ndp_fm_* (forward / next-frame model), ndp_fm_backward, ndp_fm_side_stream */
 
 #define NDP_OK            0
 #define NDP_E_ARG         1      /* bad argument (shape, alignment, null) */
@@ -306,6 +306,13 @@ int64_t ndp_encoder_param_floats(void);
 int64_t ndp_encoder_workspace_floats(int64_t n_images);
 int ndp_encoder_forward(const float *packed_params, const float *images, int64_t n_images,
                         float *codes, float *workspace, void *stream);
+/* The same from DECODED CAMERA FRAMES: frames_hwc [n][128][128][3] bytes (what PIL's JPEG decoder hands the
+ * reference's loader, utils/trajectory_loader.py:48-56).  The reference turns them into its [-1, 1] float tensors on
+ * the host -- utils/hdf5_load.py:9-11: (ToTensor()(image) - 0.5) * 2.0, ToTensor = byte -> float32, / 255 -- permutes to
+ * CHW and uploads 4 bytes per value (train_gan.py:119-124).  Here the first convolution gathers from the bytes and
+ * applies the same three fp32 operations (a 256-entry table): bit-identical codes from a quarter of the upload. */
+int ndp_encoder_forward_u8(const float *packed_params, const uint8_t *frames_hwc, int64_t n_images,
+                           float *codes, float *workspace, void *stream);
 
 /* ------------------------------------------- forward (next-frame) model ---
  * models.forward_encoder.ForwardAutoencoder (forward_encoder.py:20-114) and one iteration
@@ -356,6 +363,15 @@ int ndp_fm_train_grads(const float *params, float *running_stats, const float *s
  * events); ndp_fm_side_stream(0) keeps every launch on the caller's stream (per-kernel timing; stream capture: the fork
  * captures, but the HIP graph of it replayed at 3.9 ms against 2.0 ms eager -- and a graph of the single-stream step
  * gains nothing over eager either), returns the previous setting. */
+/* ndp_fm_forward / ndp_fm_train_grads from byte frames [n][128][128][3] (see ndp_encoder_forward_u8): state_cur and
+ * state_fut are normalised where they are read (the input gather and the loss), outputs are as above. */
+int ndp_fm_forward_u8(const float *params, float *running_stats, const uint8_t *frames_cur,
+                      const float *actions, int64_t n_images, int training, float *out,
+                      float *workspace, void *stream);
+int ndp_fm_train_grads_u8(const float *params, float *running_stats, const uint8_t *frames_cur,
+                          const uint8_t *frames_fut, const float *actions, int64_t n_images,
+                          float *grad, float *loss, float *loss_sum, float *resid_out,
+                          float *workspace, void *stream);
 int ndp_fm_side_stream(int on);
 /* Gradient buckets for a data-parallel driver (the reference trains on one device: train_forward_model.py:62; the
  * north star asks for the all-reduce of the gradients "overlapped with backward").  ndp_fm_grad_buckets writes the 7

@@ -17,7 +17,7 @@ ACTION_DIM = 4
 MAX_NOISE_DIM = 16
 MAX_SAMPLES = 256
 ROW_PAD = 32
-EXPECTED_VERSION = 133          # NDP_VERSION of include/ndp.h this binding was written against
+EXPECTED_VERSION = 134          # NDP_VERSION of include/ndp.h this binding was written against
 
 _lib = None
 
@@ -99,6 +99,7 @@ SIGNATURES = {
     "ndp_encoder_param_floats": (c_int64, []),
     "ndp_encoder_workspace_floats": (c_int64, [c_int64]),
     "ndp_encoder_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "ndp_encoder_forward_u8": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "ndp_fm_param_floats": (c_int64, []),
     "ndp_fm_stat_floats": (c_int64, []),
     "ndp_fm_workspace_floats": (c_int64, [c_int64]),
@@ -108,6 +109,9 @@ SIGNATURES = {
     "ndp_fm_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "ndp_fm_train_grads": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),
+    "ndp_fm_forward_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "ndp_fm_train_grads_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p]),
     "ndp_fm_side_stream": (c_int, [c_int]),
     "ndp_fm_grad_buckets": (c_int, [POINTER(c_int64), POINTER(c_int64), c_int]),
     "ndp_fm_bucket_wait": (c_int, [c_int, c_void_p]),

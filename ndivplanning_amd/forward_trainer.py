@@ -45,25 +45,30 @@ class ForwardModelTrainer:
             _capi.check(self.lib.ndp_fm_pack_params(_capi.ptr(self.params), _capi.ptr(self.workspace),
                                                     _capi.stream_ptr(dev)), "ndp_fm_pack_params")
 
-    def _check(self, t, shape, what):
-        if t.device != self.device or t.dtype != torch.float32 or tuple(t.shape) != shape or not t.is_contiguous():
-            raise _capi.NdpError("%s: expected a contiguous float32 %s tensor on %s, got %s %s on %s"
-                                 % (what, list(shape), self.device, t.dtype, list(t.shape), t.device))
+    def _check(self, t, shape, what, dtype=torch.float32):
+        if t.device != self.device or t.dtype != dtype or tuple(t.shape) != shape or not t.is_contiguous():
+            raise _capi.NdpError("%s: expected a contiguous %s %s tensor on %s, got %s %s on %s"
+                                 % (what, dtype, list(shape), self.device, t.dtype, list(t.shape), t.device))
 
     def grads(self, state_cur, state_fut, actions):
-        """forward + loss + backward: fills .grad, .loss (device scalar, the reference's `loss`), adds it to .loss_sum."""
+        """forward + loss + backward: fills .grad, .loss (device scalar, the reference's `loss`), adds it to .loss_sum.
+        Frames: the reference's float tensors [n,3,128,128] in [-1,1], or decoded camera frames as bytes [n,128,128,3]
+        (normalised by the kernels as they read them: utils/hdf5_load.py:9-11's formula, a quarter of the upload)."""
         n = int(state_cur.shape[0])
         if not 1 <= n <= self.batch:
             raise _capi.NdpError("batch of %d images with a trainer built for at most %d" % (n, self.batch))
-        self._check(state_cur, (n, 3, 128, 128), "state_cur")
-        self._check(state_fut, (n, 3, 128, 128), "state_fut")
+        u8 = state_cur.dtype == torch.uint8
+        shape = (n, 128, 128, 3) if u8 else (n, 3, 128, 128)
+        self._check(state_cur, shape, "state_cur", state_cur.dtype if u8 else torch.float32)
+        self._check(state_fut, shape, "state_fut", torch.uint8 if u8 else torch.float32)
         self._check(actions, (n, 4), "actions")
         p = _capi.ptr
+        fn, name = ((self.lib.ndp_fm_train_grads_u8, "ndp_fm_train_grads_u8") if u8
+                    else (self.lib.ndp_fm_train_grads, "ndp_fm_train_grads"))
         with torch.cuda.device(self.device):
-            _capi.check(self.lib.ndp_fm_train_grads(p(self.params), p(self.stats), p(state_cur), p(state_fut), p(actions), n,
-                                                    p(self.grad), p(self.loss), p(self.loss_sum),
-                                                    p(self.resid) if self.resid is not None else None,
-                                                    p(self.workspace), _capi.stream_ptr(self.device)), "ndp_fm_train_grads")
+            _capi.check(fn(p(self.params), p(self.stats), p(state_cur), p(state_fut), p(actions), n,
+                           p(self.grad), p(self.loss), p(self.loss_sum), p(self.resid) if self.resid is not None else None,
+                           p(self.workspace), _capi.stream_ptr(self.device)), name)
         return self.loss
 
     def apply(self):

@@ -261,17 +261,22 @@ class ForwardAutoencoder(nn.Module):
         if cache["ws"] is None or cache["n"] < n:
             cache["ws"] = torch.empty(lib.ndp_fm_workspace_floats(n), dtype=torch.float32, device=dev)
             cache["n"], cache["packed"] = n, False
-        x = state_cur.detach().contiguous().float()
+        u8 = state_cur.dtype == torch.uint8                 # decoded frames [n,128,128,3]: normalised by the kernels
+        if u8 and tuple(state_cur.shape[1:]) != (128, 128, 3):
+            raise _capi.NdpError("byte frames must be [n,128,128,3], got %s" % (tuple(state_cur.shape),))
+        x = state_cur.detach().contiguous() if u8 else state_cur.detach().contiguous().float()
         a = actions.detach().contiguous().float()
-        out = torch.empty_like(x)
+        out = torch.empty(n, 3, 128, 128, dtype=torch.float32, device=dev)
         cache["serial"], cache["consumed"] = cache.get("serial", 0) + 1, False     # which forward the workspace holds
         with _capi.on_device(x):
             st = _capi.stream_ptr(dev)
             if not cache["packed"]:
                 _capi.check(lib.ndp_fm_pack_params(_capi.ptr(cache["params"]), _capi.ptr(cache["ws"]), st), "ndp_fm_pack_params")
                 cache["packed"] = True
-            _capi.check(lib.ndp_fm_forward(_capi.ptr(cache["params"]), _capi.ptr(cache["stats"]), _capi.ptr(x), _capi.ptr(a), n,
-                                           1 if self.training else 0, _capi.ptr(out), _capi.ptr(cache["ws"]), st), "ndp_fm_forward")
+            fn = lib.ndp_fm_forward_u8 if u8 else lib.ndp_fm_forward
+            _capi.check(fn(_capi.ptr(cache["params"]), _capi.ptr(cache["stats"]), _capi.ptr(x), _capi.ptr(a), n,
+                           1 if self.training else 0, _capi.ptr(out), _capi.ptr(cache["ws"]), st),
+                        "ndp_fm_forward_u8" if u8 else "ndp_fm_forward")
         if self.training:                                  # batch statistics moved the running ones: hand them to the module
             with torch.no_grad():
                 for i, name in enumerate(BN_NAMES):

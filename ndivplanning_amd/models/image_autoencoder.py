@@ -41,6 +41,17 @@ class Encoder(nn.Module):
         # mpc_eval.py:139-140) with grad mode on and the loaded parameters still requiring grad: an eval-mode forward
         # is therefore NOT differentiable with respect to the encoder's parameters here; only an input that itself
         # requires grad (or training mode) selects the PyTorch operators.
+        if x.dtype == torch.uint8:
+            # decoded camera frames [n,128,128,3] (bytes, HWC): the first convolution normalises them as it gathers
+            # (utils/hdf5_load.py:9-11's formula) -- eval mode only, the GAN path's case
+            if self.training:
+                raise RuntimeError("byte frames are accepted by the eval-mode Encoder only (normalise them for training: "
+                                   "(x / 255 - 0.5) * 2, NCHW)")
+            if not x.is_cuda:
+                from .. import _capi
+                raise _capi.NdpError("frames are on %s: the eval-mode Encoder computes only on a ROCm GPU (no CPU fallback)"
+                                     % x.device)
+            return _encoder_forward_hip(self, x)
         if not self.training and not (torch.is_grad_enabled() and x.requires_grad):
             if not x.is_cuda:
                 # the GAN path's case has no CPU or eager fallback, like Decoder / Discriminator
@@ -93,9 +104,14 @@ def _encoder_state_key(enc):
 def _encoder_forward_hip(enc, x):
     from .. import _capi
     lib = _capi.load()
-    _capi.require_gpu_f32(x, "images")
-    if x.dim() != 4 or tuple(x.shape[1:]) != (3, 128, 128):
-        raise _capi.NdpError("Encoder expects images [n,3,128,128], got %s" % (tuple(x.shape),))
+    u8 = x.dtype == torch.uint8
+    if u8:
+        if x.dim() != 4 or tuple(x.shape[1:]) != (128, 128, 3):
+            raise _capi.NdpError("Encoder expects byte frames [n,128,128,3], got %s" % (tuple(x.shape),))
+    else:
+        _capi.require_gpu_f32(x, "images")
+        if x.dim() != 4 or tuple(x.shape[1:]) != (3, 128, 128):
+            raise _capi.NdpError("Encoder expects images [n,3,128,128], got %s" % (tuple(x.shape),))
     key = _encoder_state_key(enc)
     cache = enc.__dict__.get("_ndp_packed")
     if cache is None or cache[0] != key or cache[1].device != x.device:
@@ -115,6 +131,7 @@ def _encoder_forward_hip(enc, x):
         ws = torch.empty(need, device=x.device, dtype=torch.float32)
         enc.__dict__["_ndp_ws"] = ws
     with torch.cuda.device(x.device):
-        _capi.check(lib.ndp_encoder_forward(_capi.ptr(cache[1]), _capi.ptr(x), n, _capi.ptr(codes), _capi.ptr(ws),
-                                            _capi.stream_ptr()), "ndp_encoder_forward")
+        fn = lib.ndp_encoder_forward_u8 if u8 else lib.ndp_encoder_forward
+        _capi.check(fn(_capi.ptr(cache[1]), _capi.ptr(x), n, _capi.ptr(codes), _capi.ptr(ws), _capi.stream_ptr()),
+                    "ndp_encoder_forward_u8" if u8 else "ndp_encoder_forward")
     return codes.view(n, 128, 1, 1)

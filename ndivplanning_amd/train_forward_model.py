@@ -99,7 +99,7 @@ def train(config):
         display = None
 
     dataset = make_dataset(config)
-    if getattr(dataset, "mode", "images") != "images":
+    if getattr(dataset, "mode", "images") not in ("images", "frames_u8"):
         raise ValueError("the forward model trains on images: use `synthetic:<N>:images` or an HDF5 directory")
     loader = data.DataLoader(dataset, batch_size=batch_size, shuffle=True)
 
@@ -133,7 +133,9 @@ def train(config):
                     continue
                 lo, hi = dp.shard_bounds(batch_size, rank, world)
                 images, actions = images[lo:hi], actions[lo:hi]
-            images = images.to(device, non_blocking=True).float()
+            images = images.to(device, non_blocking=True)
+            if images.dtype != torch.uint8:                          # byte frames [B,T,128,128,3]: normalised by the kernels
+                images = images.float()
             actions = actions.to(device, non_blocking=True).float()
             for image_num in range(dataset.seq_length - 1):          # train_forward_model.py:98-112
                 trainer.step(images[:, image_num].contiguous(), images[:, image_num + 1].contiguous(),

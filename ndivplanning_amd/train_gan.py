@@ -18,7 +18,7 @@ What differs from the reference, on purpose:
   * the forward-model checkpoints the reference loads and never uses (train_gan.py:79-86) are
     not loaded; visdom plotting is attempted only if visdom is importable.
 
-Extra YAML keys (all optional): `train_data_path: synthetic:<N>[:codes|images]` for seeded
+Extra YAML keys (all optional): `train_data_path: synthetic:<N>[:codes|images|frames_u8]` for seeded
 synthetic trajectories, `training.gan.noise_source`, `training.gan.use_graph`,
 `training.gan.steps_per_launch` (iterations per HIP-graph launch, default 16; the batches of one
 launch are staged into separate input slots, the arithmetic is unchanged),
@@ -92,7 +92,9 @@ def make_dataset(config):
         n = int(spec[1])
         mode = spec[2] if len(spec) > 2 else "codes"
         return SyntheticPushDataset(n, seq_length=config.trajectory_length, mode=mode, seed=int(config.random_seed))
-    return PushDataset(config.train_data_path, seq_length=config.trajectory_length)
+    # decoded frames stay bytes until the first convolution reads them (ndp_encoder_forward_u8 / ndp_fm_*_u8):
+    # `raw_uint8: false` restores the reference's host-side float tensors
+    return PushDataset(config.train_data_path, seq_length=config.trajectory_length, raw_uint8=bool(_get(config, "raw_uint8", True)))
 
 
 def load_encoder(config, device):
@@ -176,7 +178,7 @@ def train(config):
     if n_batches == 0:
         raise ValueError("dataset of %d trajectories is smaller than one batch of %d" % (len(dataset), batch_size))
     seq_length = int(dataset.seq_length)
-    image_mode = getattr(dataset, "mode", "images") == "images"
+    image_mode = getattr(dataset, "mode", "images") in ("images", "frames_u8")
     encoder = load_encoder(config, device) if image_mode else None
 
     decoder = Decoder(noise_dim=noise_dim)
@@ -247,7 +249,10 @@ def train(config):
                 per_frame, actions = code_cache[mine], action_cache[mine]
             else:
                 frames, _states, actions, _goal = next(loader)
-                frames = frames[lo:hi].float().to(device, non_blocking=True)
+                frames = frames[lo:hi]
+                if frames.dtype != torch.uint8:                      # byte frames [B,T,128,128,3] are uploaded as they are
+                    frames = frames.float()
+                frames = frames.to(device, non_blocking=True)
                 actions = actions[lo:hi].float().to(device, non_blocking=True)
                 if frames.dim() == 5:
                     with torch.no_grad():

@@ -38,7 +38,7 @@ class GanTrainer:
     def __init__(self, decoder: Decoder, discriminator: Discriminator, *, flat: int, num_sample: int,
                  lr: float = 2e-4, betas=(0.5, 0.999), eps: float = 1e-8, pairwise_div_factor: float = 0.1,
                  discrim_steps: int = 1, flat_global: int = None, reduce_fn=None, use_graph: bool = True,
-                 noise_seed: int = 0, steps_per_launch: int = 1, p2p=None):
+                 noise_seed: int = 0, steps_per_launch: int = 1, p2p=None, copy_stream=None):
         self.lib = _capi.load()
         self.decoder, self.discriminator = decoder, discriminator
         self.noise_dim = decoder.noise_dim
@@ -95,6 +95,10 @@ class GanTrainer:
             raise _capi.NdpError("bad step configuration (flat=%d, num_sample=%d)" % (self.flat, self.k))
         self.workspace = torch.empty(nws, **f32)
         self._graphs = None
+        # step_many_from_host uploads on this stream (default: one of its own).  A process should keep the number of
+        # streams it really uses small: beyond ~4 hardware queues the GPU time-slices them instead of running them side
+        # by side (measured: every kernel of a two-stream workload 2-4x slower once two more streams had been used)
+        self._copy_stream = copy_stream
         self._stage = None
         self._alt_slots = None
         self._device_noise_now = False
@@ -318,7 +322,7 @@ class GanTrainer:
         if not (codes_host.is_pinned() and actions_host.is_pinned()):
             raise ValueError("step_many_from_host needs pinned host tensors (torch.Tensor.pin_memory())")
         if self._stage is None:
-            self._stage = {"stream": torch.cuda.Stream(self.device), "next": 0,
+            self._stage = {"stream": self._copy_stream or torch.cuda.Stream(self.device), "next": 0,
                            "uploaded": [torch.cuda.Event(), torch.cuda.Event()],
                            "read": [torch.cuda.Event(), torch.cuda.Event()]}
             # the second slot set is allocated (and zero-filled) on the launch stream: the copy stream must not

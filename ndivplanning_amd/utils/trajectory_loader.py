@@ -16,11 +16,12 @@ from .argparse_util import listdir_nohidden
 
 class SyntheticPushDataset(torch.utils.data.Dataset):
     """Seeded random trajectories.  mode 'images': frames ~ U[-1,1) [T,3,128,128];
-    mode 'codes': frame codes ~ N(0,1) [T,128] in place of the images."""
+    mode 'codes': frame codes ~ N(0,1) [T,128] in place of the images; mode 'frames_u8': decoded camera frames as the
+    JPEG decoder leaves them, bytes [T,128,128,3] (what `PushDataset(raw_uint8=True)` yields)."""
 
     def __init__(self, num_trajectories, seq_length=8, mode="codes", seed=0, image_size=128):
-        if mode not in ("codes", "images"):
-            raise ValueError("mode must be 'codes' or 'images'")
+        if mode not in ("codes", "images", "frames_u8"):
+            raise ValueError("mode must be 'codes', 'images' or 'frames_u8'")
         self.n, self.seq_length, self.mode, self.seed, self.hw = int(num_trajectories), int(seq_length), mode, seed, image_size
 
     def __len__(self):
@@ -31,6 +32,8 @@ class SyntheticPushDataset(torch.utils.data.Dataset):
         t = self.seq_length
         if self.mode == "codes":
             frames = torch.randn(t, 128, generator=gen)
+        elif self.mode == "frames_u8":
+            frames = torch.randint(0, 256, (t, self.hw, self.hw, 3), generator=gen, dtype=torch.uint8)
         else:
             frames = torch.rand(t, 3, self.hw, self.hw, generator=gen) * 2.0 - 1.0
         states = torch.randn(t, 25, generator=gen)
@@ -39,10 +42,20 @@ class SyntheticPushDataset(torch.utils.data.Dataset):
         return frames, states, actions, goal
 
 
+def norm_frame(image):
+    """utils/hdf5_load.py:9-11, `(ToTensor()(image) - 0.5) * 2.0`, without torchvision: ToTensor is bytes HWC -> CHW,
+    float32, divided by 255."""
+    t = torch.from_numpy(np.array(image, dtype=np.uint8)).permute(2, 0, 1).contiguous()
+    return (t.to(torch.float32).div(255) - 0.5) * 2.0
+
+
 class PushDataset(torch.utils.data.Dataset):
     """The reference's HDF5 + JPEG dataset (utils/trajectory_loader.py:17-72)."""
 
-    def __init__(self, datadir, seq_start=0, seq_length=15, transform=None):
+    def __init__(self, datadir, seq_start=0, seq_length=15, transform=None, raw_uint8=False):
+        # raw_uint8: images as the decoder's bytes [T,H,W,3] instead of the normalised float tensor [T,3,H,W]; the
+        # kernels apply the reference's normalisation (utils/hdf5_load.py:9-11) as they read (a quarter of the upload)
+        self.raw_uint8 = bool(raw_uint8)
         try:
             import h5py  # noqa: F401
             from PIL import Image  # noqa: F401
@@ -75,8 +88,8 @@ class PushDataset(torch.utils.data.Dataset):
             seq = f["trajectory_{:05d}".format(seq_index)]
             frames = []
             for b in seq["images"][sl]:
-                img = np.asarray(Image.open(io.BytesIO(b.tobytes() if hasattr(b, "tobytes") else b)), dtype=np.float32)
-                frames.append(torch.from_numpy((img / 255.0 - 0.5) * 2.0).permute(2, 0, 1))
+                img = Image.open(io.BytesIO(b.tobytes() if hasattr(b, "tobytes") else b))
+                frames.append(torch.from_numpy(np.array(img, dtype=np.uint8)) if self.raw_uint8 else norm_frame(img))
             images = torch.stack(frames)
             states = torch.from_numpy(seq["states"][sl])
             actions = torch.from_numpy(seq["actions"][sl])

@@ -57,3 +57,24 @@ def test_folded_packed_parameters_give_the_same_codes():
     import pytest
     with pytest.raises(NdpError):
         enc(x)
+
+
+def test_byte_frames_decode_and_normalise_as_the_reference_loader_does():
+    """tests/golden/frames_case.npz: JPEG bytes -> PIL -> bytes HWC -> (ToTensor - 0.5) * 2 (utils/hdf5_load.py:9-11) ->
+    the reference Encoder's codes.  Here: this image's PIL decodes the stored JPEGs to the stored bytes, the mirror's
+    `norm_frame` and the 256-entry table both give the formula's floats, and the oracle reproduces the stored codes."""
+    import io
+    from PIL import Image
+    from ndivplanning_amd.utils.trajectory_loader import norm_frame
+    g = load_golden("frames_case")
+    decoded = np.stack([np.array(Image.open(io.BytesIO(g[k].tobytes())), dtype=np.uint8) for k in ("jpeg0", "jpeg1")])
+    assert decoded.shape == (2, 128, 128, 3) and np.array_equal(decoded, g["frames_u8"])
+    assert int(g["byte_values_present"][0]) == 256                      # every byte value is exercised
+    lut = ((torch.arange(256, dtype=torch.uint8).to(torch.float32).div(255) - 0.5) * 2.0).numpy()
+    assert np.array_equal(lut, g["lut"]) and lut[0] == -1.0 and lut[255] == 1.0
+    x = torch.stack([norm_frame(Image.open(io.BytesIO(g[k].tobytes()))) for k in ("jpeg0", "jpeg1")])
+    assert x.shape == (2, 3, 128, 128) and np.array_equal(x.numpy(), g["lut"][g["frames_u8"]].transpose(0, 3, 1, 2))
+    seed, bn_seed = (int(v) for v in g["seeds"])
+    torch.set_num_threads(1)
+    codes = EO.encoder_forward(EO.init_encoder_state(seed, bn_seed=bn_seed), x).reshape(2, 128).numpy()
+    assert np.abs(codes - g["codes"]).max() <= 1e-6 * np.abs(g["codes"]).max()

@@ -133,3 +133,40 @@ def test_config4_image_conditioned_step_at_batch_128():
     assert (tr.action_hat[:tr.m].cpu() - ref["action_hat"]).abs().max().item() <= 1e-4
     g0 = torch.cat([v.reshape(-1) for v in g.values()]).to(DEV)
     assert 0 < (tr.g_flat - g0).abs().max().item() <= 2.5 * 2e-4            # one Adam step happened, inside its bound
+
+
+def test_byte_frames_give_the_float_path_s_codes_bit_for_bit_and_the_reference_s():
+    """ndp_encoder_forward_u8: decoded camera frames [n,128,128,3] as bytes, normalised by conv1 as it gathers
+    (utils/hdf5_load.py:9-11's formula as a 256-entry table).  Against (a) the float path fed the tensor the reference's
+    loader would have built from the same bytes -- bit-identical, the arithmetic after the table is the same -- and (b) the
+    codes of the reference's own Encoder on that tensor (tests/golden/frames_case.npz)."""
+    from ndivplanning_amd import _capi
+    from ndivplanning_amd.models.image_autoencoder import Encoder
+    g = load_golden("frames_case")
+    seed, bn_seed = (int(v) for v in g["seeds"])
+    enc = Encoder()
+    enc.load_state_dict(EO.init_encoder_state(seed, bn_seed=bn_seed), strict=False)
+    enc = enc.to(DEV).eval()
+    frames = torch.from_numpy(g["frames_u8"])
+    x = torch.from_numpy(g["lut"][g["frames_u8"]].transpose(0, 3, 1, 2).copy())
+    _capi.timing_enable(True)
+    with torch.no_grad():
+        got_u8 = enc(frames.to(DEV)).reshape(2, 128)
+        got_f32 = enc(x.to(DEV)).reshape(2, 128)
+    torch.cuda.synchronize()
+    timed = _capi.timing_collect()
+    _capi.timing_enable(False)
+    assert timed["k_enc_conv1"][1] == 2                                 # both went through the HIP kernels
+    assert torch.equal(got_u8, got_f32)
+    scale = np.abs(g["codes"]).max()
+    assert np.abs(got_u8.cpu().numpy() - g["codes"]).max() <= 1e-4 * scale
+    # a bigger batch of random bytes (every value, every border case of the 3x3 stride-2 gather)
+    gen = torch.Generator().manual_seed(3)
+    frames = torch.randint(0, 256, (37, 128, 128, 3), generator=gen, dtype=torch.uint8)
+    x = torch.from_numpy(g["lut"])[frames.long()].permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        assert torch.equal(enc(frames.to(DEV)), enc(x.to(DEV)))
+    with pytest.raises(_capi.NdpError):
+        enc(frames[:, :, :, :2].contiguous().to(DEV))                    # not [n,128,128,3]
+    with pytest.raises(_capi.NdpError):
+        enc(frames)                                                     # CPU bytes: no fallback either

@@ -521,3 +521,32 @@ def test_weight_init_after_a_forward_is_seen_by_the_next_forward():
         y2 = model(x, a)
         want2 = FO.forward({k: v.cpu() for k, v in model.state_dict().items()}, x.cpu(), a.cpu(), training=False)
         assert (y2 - y1).abs().max().item() > 1e-2 and (y2.cpu() - want2).abs().max().item() <= 5e-5
+
+
+def test_byte_frames_train_exactly_as_the_floats_the_reference_would_upload():
+    """ndp_fm_train_grads_u8 / ndp_fm_forward_u8: frames [n,128,128,3] as bytes, normalised where they are read (the input
+    gather and the loss target) with utils/hdf5_load.py:9-11's formula.  Two training iterations from byte frames and from
+    the float tensors built from the same bytes give bit-identical losses, gradients and parameters."""
+    lut = torch.from_numpy(load_golden("frames_case")["lut"])
+    gen = torch.Generator().manual_seed(21)
+    frames = torch.randint(0, 256, (3, 3, 128, 128, 3), generator=gen, dtype=torch.uint8)      # [n, t, H, W, C]
+    actions = torch.rand(3, 3, 4, generator=gen) * 2 - 1
+    floats = lut[frames.long()].permute(0, 1, 4, 2, 3).contiguous()                            # [n, t, 3, H, W]
+    tr8, _ = _hip_trainer(5, 3, keep_residual=True)
+    trf, _ = _hip_trainer(5, 3, keep_residual=True)
+    for it in range(2):
+        act = actions[:, it].contiguous().to(DEV)
+        tr8.step(frames[:, it].contiguous().to(DEV), frames[:, it + 1].contiguous().to(DEV), act)
+        grad8 = tr8.grad.clone()
+        trf.step(floats[:, it].contiguous().to(DEV), floats[:, it + 1].contiguous().to(DEV), act)
+        assert torch.equal(tr8.loss, trf.loss) and torch.equal(tr8.resid, trf.resid)
+        assert torch.equal(grad8, trf.grad) and torch.equal(tr8.params, trf.params)
+    assert float(tr8.loss) > 0
+    with pytest.raises(Exception):
+        tr8.step(frames[:, 0].contiguous().to(DEV), floats[:, 1].contiguous().to(DEV), actions[:, 0].contiguous().to(DEV))
+    # the module's eval-mode forward (state_cur + residual) from bytes
+    model = tr8.sync_to_module().eval()
+    with torch.no_grad():
+        y8 = model(frames[:, 0].contiguous().to(DEV), actions[:, 0].contiguous().to(DEV))
+        yf = model(floats[:, 0].contiguous().to(DEV), actions[:, 0].contiguous().to(DEV))
+    assert y8.shape == (3, 3, 128, 128) and torch.equal(y8, yf)
