@@ -20,8 +20,12 @@ def _inputs(data_seed, n):
     return frames, actions
 
 
-def test_two_training_iterations_match_the_reference():
-    g = load_golden("forward_model_case")
+import pytest
+
+
+@pytest.mark.parametrize("case", ["forward_model_case", "forward_model_case_sharp"])
+def test_two_training_iterations_match_the_reference(case):
+    g = load_golden(case)
     seed, data_seed, n = (int(v) for v in g["meta"])
     torch.set_num_threads(1)
     state = FO.init_forward_model_state(seed)

@@ -489,6 +489,61 @@ def test_free_running_vs_oracle(batch, k):
             assert abs(pd - ref["pair_div"].item()) <= rtol * abs(ref["pair_div"].item())
 
 
+def test_fifty_free_running_steps_at_config_1_stay_near_the_oracle():
+    """Long-run drift, BASELINE configs[0] (batch 16, K = 6, FLAT = 112): 50 consecutive iterations with NO forcing, a fresh
+    batch and fresh noise every step, against the oracle run the same way in fp32 (the reference's arithmetic, torch CPU)
+    and in fp64 (the adjudicator).
+
+    What bounds the drift.  Two correct fp32 implementations differ per step by summation order (~1e-7 relative in a
+    gradient).  Adam turns that into parameter differences where an element's gradient is inside its own noise floor (the
+    update is lr * m / (sqrt(v) + eps): a sign disagreement moves that element by up to 2 lr = 4e-4), one NDiv hinge term
+    whose margin is inside rounding can flip, and NDiv divides by the ~1e-3 spread of the K samples
+    of a row, so parameter differences of 1e-3 move it by per cent.  These differences feed back through 50 updates: the
+    trajectories of ANY two fp32 implementations separate -- the reference's own fp32 run from an fp64 run of the same code
+    included.  So the bound is adjudicated, as the gradient checks are: at every step the HIP path may be as far from the
+    fp64 trajectory as 4 x the fp32 oracle's worst distance from it over the run, or the absolute floors below, whichever
+    is larger.  Measured on MI355X (printed with -s): HIP vs fp32 oracle D / G losses within 1e-4 / 9e-4 over the 50
+    steps, NDiv within 15 %, parameters within 1.3e-2; a wrong formula is off by O(1) within a few steps."""
+    from ndivplanning_amd.trainer import GanTrainer
+    batch, k, steps = 16, 6, 50
+    g, d = O.init_params(0, 2)
+    sm32 = O.StepMath({n: v.clone() for n, v in g.items()}, {n: v.clone() for n, v in d.items()})
+    sm64 = O.StepMath({n: v.double().clone() for n, v in g.items()}, {n: v.double().clone() for n, v in d.items()})
+    dec, dis = _load_modules(g, d, 2)
+    tr = GanTrainer(dec, dis, flat=batch * 7, num_sample=k)
+    keys = ("d_loss", "g_loss", "pair_div")
+    hip_dev, ref_dev, vs32 = [0.0] * 3, [0.0] * 3, [0.0] * 3
+    first = last = None
+    for s in range(steps):
+        codes, actions, noise = O.synthetic_batch(500 + s, batch, k, steps=1)
+        r32 = sm32.step(codes, actions, noise[0])
+        r64 = sm64.step(codes.double(), actions.double(), noise[0].double())
+        tr.step(codes.to(DEV), actions.to(DEV), noise[0].to(DEV))
+        mine = tr.losses()
+        for i, key in enumerate(keys):
+            scale = 1.0 if i < 2 else abs(r64[key].item())               # BCE absolute, NDiv relative
+            hip_dev[i] = max(hip_dev[i], abs(mine[i] - r64[key].item()) / scale)
+            ref_dev[i] = max(ref_dev[i], abs(r32[key].item() - r64[key].item()) / scale)
+            vs32[i] = max(vs32[i], abs(mine[i] - r32[key].item()) / scale)
+        if s == 0:
+            first = (r64["d_loss"].item(), r64["g_loss"].item())
+        last = (r64["d_loss"].item(), r64["g_loss"].item())
+
+    def pdist(mine, ref):
+        return max(float((mine[n].detach().cpu().double() - v.double()).abs().max()) for n, v in ref.items())
+    p_hip = max(pdist(tr.decoder.state_dict(), sm64.g), pdist(tr.discriminator.state_dict(), sm64.d))
+    p_ref = max(pdist(sm32.g, sm64.g), pdist(sm32.d, sm64.d))
+    report = ("distance from the fp64 trajectory, worst step (D, G absolute; NDiv relative): hip %s, fp32 oracle %s; hip vs "
+              "fp32 oracle %s; parameters hip %.2e, fp32 oracle %.2e; fp64 losses %s -> %s"
+              % (["%.2e" % v for v in hip_dev], ["%.2e" % v for v in ref_dev], ["%.2e" % v for v in vs32], p_hip, p_ref, first, last))
+    print(report)
+    assert abs(first[0] - last[0]) + abs(first[1] - last[1]) > 5e-3, report           # the run went somewhere
+    floors = (2e-4, 1e-3, 5e-2)
+    for i in range(3):
+        assert hip_dev[i] <= max(floors[i], 4.0 * ref_dev[i]), (keys[i], report)
+    assert p_hip <= max(2e-3, 4.0 * p_ref) and p_hip <= 50 * 2 * 2e-4, report            # Adam's hard bound: 2 lr per step
+
+
 def test_data_parallel_two_shards_equal_global_batch():
     """Two trainers, each with half of the rows and inv_m of the GLOBAL batch, gradients
     summed between phases (what the RCCL all-reduce does), against one trainer on the whole
