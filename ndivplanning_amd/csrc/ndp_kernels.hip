@@ -1220,7 +1220,8 @@ __device__ __forceinline__ void adam_advance(int32_t* state, float lr, float b1,
 //   SKINNY_A  (<=16) j x 64 k   (the 4- and 1-wide output layers)
 // Workgroup (job, chunk): the 4 waves take interleaved 4-row steps of the chunk's rows,
 // accumulate in registers, then add their four results through LDS and store one slab.
-enum { WG_FULL = 0, WG_SKINNY_B = 1, WG_SKINNY_A = 2 };
+//   WIDE      256 j x 128 k: a whole layer's dW (D.fc3, G.fc4) per workgroup, operands staged through LDS (large M)
+enum { WG_FULL = 0, WG_SKINNY_B = 1, WG_SKINNY_A = 2, WG_WIDE = 3 };
 #ifndef NDP_WGRAD_PFG
 #define NDP_WGRAD_PFG 8     // 4-row steps in the operand prefetch ring
 #endif
@@ -1246,7 +1247,9 @@ struct WgradJob {
 };
 constexpr int kMaxJobs = 28;
 struct WgradHead {     // what every workgroup reads: first in the argument struct, a few cache lines (see k_wgrad)
-  int njobs;
+  int njobs;           // 64 x 64 (and skinny) jobs: job[0 .. njobs)
+  int nwide;           // WIDE jobs: job[njobs .. njobs + nwide), each over wide_chunks row chunks; their workgroups come
+  int wide_chunks;     // FIRST in the grid (the longest); nwide * wide_chunks is a multiple of 8
   int rows;            // total rows (multiple of 16)
   float* slabs;        // [nchunks][slab_stride]
   int64_t slab_stride;
@@ -1259,6 +1262,7 @@ struct WgradArgs : WgradHead {
   WgradJob job[kMaxJobs];
   int net_is_g;        // host side only: kernel timing label
   int nreg, reg_begin[4], reg_end[4];   // host side only: layers whose jobs are "light" (fewer chunks)
+  int wide_begin, wide_end;             // host side only: the parameter range the WIDE job writes
 };
 
 #ifdef NDP_STAMPS
@@ -1427,28 +1431,122 @@ __device__ __forceinline__ void wgrad_block(const WgradJob& jb, int rbeg, int re
   }
 }
 
-constexpr int wgrad_lds_floats() { return kWaves * 64 * 64 + kWaves * 64; }
+// WIDE job: dW [256 x 128] = sum over the chunk's rows of dY[row][0..256) x X[row][0..128), one workgroup, every wave
+// over ALL rows: wave w owns the 64 j of tile w and all 128 k (32 accumulator tiles = 128 registers).  The register-fed
+// 64 x 64 blocks above fetch 2 KB per 16 MFMAs and wave -- 16 B/clk per CU from L2, which is what the memory pipe gives
+// beyond L1 (counters at B = 128 / K = 32: matrix pipe 28 % busy, L2 hit rate 48 %, the eight jobs of this layer read
+// every activation byte 2.7 times).  Here slabs of 16 rows (24 KB: 16 x 256 floats of dY, 16 x 128 of X) go global ->
+// LDS by LDS-DMA (global_load_lds_dwordx4: no register round trip), three buffers, TWO slabs in flight while one is
+// multiplied (a slab is 128 MFMAs per wave, ~4,100 cycles; an HBM miss under load is longer than that): a counted
+// s_waitcnt leaves the next slab's loads pending across the one raw barrier per slab.  6 B/clk per CU from L2.
+// Chunks are whole slabs (rows are padded to 32 and chunk bounds to 16), so no row needs masking.
+constexpr int kWideR = 16, kWideSlab = kWideR * (256 + 128);
+constexpr int wgrad_wide_lds_floats() { return 3 * kWideSlab; }
+__device__ __forceinline__ void wgrad_wide(const WgradJob& jb, int rbeg, int rend, float* slab, float* smem) {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  f32x4 acc[4][8];
+  float bs[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    bs[u] = 0.f;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) acc[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int nslabs = rend > rbeg ? (rend - rbeg) / kWideR : 0;
+  // one wave-instruction writes 1 KB of LDS, lane i at base + 16 i: a whole dY row (wave w: rows w, w + 4, w + 8, w + 12),
+  // or two X rows (wave w: row pairs w and w + 4; lanes 0..31 the first row of the pair)
+  auto fetch = [&](int s) {
+    float* buf = smem + (s % 3) * kWideSlab;
+    const size_t r0 = (size_t)rbeg + (size_t)s * kWideR;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave + 4 * i;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(jb.A + (r0 + row) * jb.lda + 4 * lane), (lds_ptr_t)(buf + row * 256), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pair = wave + 4 * i;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(jb.B + (r0 + 2 * pair + (lane >> 5)) * jb.ldb + 4 * (lane & 31)),
+                                       (lds_ptr_t)(buf + kWideR * 256 + pair * 256), 16, 0, 0);
+    }
+  };
+  if (nslabs > 0) fetch(0);
+  if (nslabs > 1) fetch(1);
+  for (int s = 0; s < nslabs; ++s) {
+    // slab s has landed (this wave's share: all but the 6 loads of slab s + 1, if any), for every wave: barrier.  The
+    // barrier also says every wave is done reading the buffer of slab s - 1, which slab s + 2 then overwrites.
+    if (s + 1 < nslabs) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (s + 2 < nslabs) fetch(s + 2);
+    const float* As = smem + (s % 3) * kWideSlab + 64 * wave + 4 * c;
+    const float* Bs = smem + (s % 3) * kWideSlab + kWideR * 256 + 4 * c;
+#pragma unroll
+    for (int st = 0; st < kWideR / 4; ++st) {
+      const f32x4 va = *reinterpret_cast<const f32x4*>(As + (4 * st + q) * 256);
+      const f32x4 vb0 = *reinterpret_cast<const f32x4*>(Bs + (4 * st + q) * 128);
+      const f32x4 vb1 = *reinterpret_cast<const f32x4*>(Bs + (4 * st + q) * 128 + 64);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        bs[u] += va[u];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          acc[u][v] = mfma16(va[u], vb0[v], acc[u][v]);
+          acc[u][4 + v] = mfma16(va[u], vb1[v], acc[u][4 + v]);
+        }
+      }
+    }
+  }
+  // C tile (u, v) of k-tile kt: the lane holds dW row j = 64 wave + 4 (4 q + i) + u, columns 64 kt + 4 c + v
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float* d = slab + jb.dst_off + (size_t)(64 * wave + 4 * (4 * q + i) + u) * jb.dst_ld + 4 * c;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+        *reinterpret_cast<f32x4*>(d + 64 * kt) = f32x4{acc[u][4 * kt][i], acc[u][4 * kt + 1][i], acc[u][4 * kt + 2][i], acc[u][4 * kt + 3][i]};
+    }
+  if (jb.bias_off >= 0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float sum = bs[u];
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      if (q == 0) slab[jb.bias_off + 64 * wave + 4 * c + u] = sum;
+    }
+  }
+}
 
-__global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a_segment) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  // Arguments (load_kernargs explains why): the head's cache lines and the two lines of this workgroup's 88-byte job
-  // entry are requested together, one wait; head and entry are then copied out through a pointer the compiler
-  // cannot trace to the kernarg segment.  The 2.5 KB table itself is never read as a whole.
+constexpr int wgrad_lds_floats() { return kWaves * 64 * 64 + kWaves * 64; }
+// dynamic LDS of k_wgrad_wide: the 64 x 64 jobs' cross-wave sum image or the WIDE job's three slabs
+constexpr int wgrad_wide_launch_lds_floats() { return wgrad_wide_lds_floats() > wgrad_lds_floats() ? wgrad_wide_lds_floats() : wgrad_lds_floats(); }
+
+// Arguments of k_wgrad (load_kernargs explains why): the head's cache lines and the two lines of this workgroup's 88-byte
+// job entry are requested together, one wait; head and entry are then copied out through a pointer the compiler cannot
+// trace to the kernarg segment.  The 2.5 KB table itself is never read as a whole.
+__device__ __forceinline__ void wgrad_fetch_args(WgradHead& a, WgradJob& jb, int& job_id, int& chunk) {
   typedef const __attribute__((address_space(4))) char* kbytes_t;
   static_assert(sizeof(WgradHead) <= 192 && offsetof(WgradArgs, job) % 8 == 0, "k_wgrad argument prefetch");
-  (void)a_segment;
-  WgradHead a;
-  WgradJob jb;
-  int job_id, chunk;
-  {
     kbytes_t kp = (kbytes_t)__builtin_amdgcn_kernarg_segment_ptr();
-    uint32_t h0, h1, h2;
-    asm volatile("s_load_dword %0, %3, 0x0\n\ts_load_dword %1, %3, 0x40\n\ts_load_dword %2, %3, 0x80\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(h0), "=&s"(h1), "=&s"(h2) : "s"(kp) : "memory");
-    const int njobs = (int)h0;                        // WgradHead::njobs is the first word
-    const int idx = blockIdx.x >> 3;
-    job_id = idx % njobs;
-    chunk = (int)(blockIdx.x & 7) + 8 * (idx / njobs);
+    uint32_t h0, h1, h2, hw0, hw1;
+    asm volatile("s_load_dword %0, %5, 0x0\n\ts_load_dword %1, %5, 0x40\n\ts_load_dword %2, %5, 0x80\n\t"
+                 "s_load_dword %3, %5, 0x4\n\ts_load_dword %4, %5, 0x8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(h0), "=&s"(h1), "=&s"(h2), "=&s"(hw0), "=&s"(hw1) : "s"(kp) : "memory");
+    const int njobs = (int)h0;                        // WgradHead::njobs, nwide, wide_chunks are the first three words
+    const int wide_blocks = (int)hw0 * (int)hw1;
+    if ((int)blockIdx.x < wide_blocks) {
+      job_id = njobs + (int)blockIdx.x / (int)hw1;
+      chunk = (int)blockIdx.x % (int)hw1;
+    } else {
+      const int b = (int)blockIdx.x - wide_blocks;
+      const int idx = b >> 3;
+      job_id = idx % njobs;
+      chunk = (b & 7) + 8 * (idx / njobs);
+    }
     const uint32_t joff = (uint32_t)(offsetof(WgradArgs, job) + (size_t)job_id * sizeof(WgradJob));
     uint32_t j0, j1;
     asm volatile("s_load_dword %0, %2, %3\n\ts_load_dword %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
@@ -1457,7 +1555,16 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a_segment) {
     asm volatile("" : "+s"(v) : "s"(h0 | h1 | h2 | j0 | j1));
     __builtin_memcpy(&a, (kbytes_t)v, sizeof(WgradHead));
     __builtin_memcpy(&jb, (kbytes_t)v + joff, sizeof(WgradJob));
-  }
+}
+
+// WIDE: the instantiation that can run WG_WIDE jobs (large M: its 128 accumulator registers leave one workgroup per CU;
+// the other keeps two)
+template <bool WIDE>
+__device__ __forceinline__ void wgrad_body(float* smem) {
+  WgradHead a;
+  WgradJob jb;
+  int job_id, chunk;
+  wgrad_fetch_args(a, jb, job_id, chunk);
   // Linear grid with an XCD-aware order: workgroups are dealt round-robin over the 8 XCDs
   // (b % 8 labels the XCD; speed only, never correctness), and every job of a row chunk reads
   // the same activation rows, so all jobs of chunk c are given to XCD c % 8: the rows then cross
@@ -1465,7 +1572,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a_segment) {
   // k_wgrad[D] 55 MB with the plain order, where each XCD fetched every chunk).
   // Blocks past the wgrad slots are NDiv blocks (the NDiv loss/gradient needs only action_hat
   // and the noise: it runs beside the D weight gradients instead of as a kernel of its own).
-  const int slots = 8 * ((a.nchunks + 7) / 8) * a.njobs;
+  const int slots = a.nwide * a.wide_chunks + 8 * ((a.nchunks + 7) / 8) * a.njobs;
   if ((int)blockIdx.x >= slots) {
     ndiv_block<4, 2>(a.nd, (int)blockIdx.x - slots, smem);
     return;
@@ -1487,7 +1594,8 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a_segment) {
 #else
   unsigned long long* wst = nullptr;
 #endif
-  if (kind == WG_FULL) wgrad_block<4, 4, WG_FULL>(jb, rbeg, rend, jrows - 1, slab, smem, wst);
+  if (WIDE && kind == WG_WIDE) wgrad_wide(jb, rbeg, rend, slab, smem);
+  else if (kind == WG_FULL) wgrad_block<4, 4, WG_FULL>(jb, rbeg, rend, jrows - 1, slab, smem, wst);
   else if (kind == WG_SKINNY_B) wgrad_block<4, 1, WG_SKINNY_B>(jb, rbeg, rend, jrows - 1, slab, smem, wst);
   else wgrad_block<1, 4, WG_SKINNY_A>(jb, rbeg, rend, jrows - 1, slab, smem, wst);
 #ifdef NDP_STAMPS
@@ -1495,6 +1603,18 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a_segment) {
   if (threadIdx.x == 0 && NDP_STAMP_ON(4))
     for (int i_ = 0; i_ < 10; ++i_) g_stamps[(size_t)blockIdx.x * 64 + i_] = wst[i_];
 #endif
+}
+
+__global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a_segment) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  (void)a_segment;
+  wgrad_body<false>(smem);
+}
+// (two workgroups per CU: at most 256 registers per lane, 128 of them the WIDE job's accumulators)
+__global__ __launch_bounds__(kThreads, 2) void k_wgrad_wide(WgradArgs a_segment) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  (void)a_segment;
+  wgrad_body<true>(smem);
 }
 
 // ================================================================ slab reduce + Adam + losses
