@@ -1440,83 +1440,107 @@ __device__ __forceinline__ void wgrad_block(const WgradJob& jb, int rbeg, int re
 // multiplied (a slab is 128 MFMAs per wave, ~4,100 cycles; an HBM miss under load is longer than that): a counted
 // s_waitcnt leaves the next slab's loads pending across the one raw barrier per slab.  6 B/clk per CU from L2.
 // Chunks are whole slabs (rows are padded to 32 and chunk bounds to 16), so no row needs masking.
-constexpr int kWideR = 16, kWideSlab = kWideR * (256 + 128);
-constexpr int wgrad_wide_lds_floats() { return 3 * kWideSlab; }
+// JW = 64-row tiles of dW per workgroup: 4 -- the whole 256 x 128 layer, wave w owns tile w and both 64-column halves (32
+// accumulator tiles); 2 -- half of it (128 x 128: two jobs per layer), wave w owns tile w >> 1 and column half w & 1 (16
+// accumulator tiles, three workgroups per CU): at the same workgroup duration the layer then needs half the row chunks,
+// i.e. half the slabs for k_reduce_adam to add.
+constexpr int kWideR = 16;
+template <int JW> constexpr int wide_slab_floats() { return kWideR * (64 * JW + 128); }
+constexpr int wgrad_wide_lds_floats() { return 3 * wide_slab_floats<4>(); }
+template <int JW>
 __device__ __forceinline__ void wgrad_wide(const WgradJob& jb, int rbeg, int rend, float* slab, float* smem) {
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+  constexpr int AW = 64 * JW;                       // dY columns of this job
+  constexpr int NK = JW == 4 ? 2 : 1;               // 64-column halves of X per wave
+  constexpr int SLAB = wide_slab_floats<JW>();
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int c = lane & 15, q = lane >> 4;
-  f32x4 acc[4][8];
+  const int jt = JW == 4 ? wave : (wave >> 1), kt0 = JW == 4 ? 0 : (wave & 1);
+  f32x4 acc[4][4 * NK];
   float bs[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     bs[u] = 0.f;
 #pragma unroll
-    for (int v = 0; v < 8; ++v) acc[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int v = 0; v < 4 * NK; ++v) acc[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int nslabs = rend > rbeg ? (rend - rbeg) / kWideR : 0;
-  // one wave-instruction writes 1 KB of LDS, lane i at base + 16 i: a whole dY row (wave w: rows w, w + 4, w + 8, w + 12),
-  // or two X rows (wave w: row pairs w and w + 4; lanes 0..31 the first row of the pair)
+  // one wave-instruction writes 1 KB of LDS, lane i at base + 16 i: a whole 256-float dY row (JW = 4; wave w: rows w, w +
+  // 4, w + 8, w + 12) or two 128-float rows (dY at JW = 2, X always; wave w: row pairs w and w + 4, lanes 0..31 the first
+  // row of the pair)
   auto fetch = [&](int s) {
-    float* buf = smem + (s % 3) * kWideSlab;
+    float* buf = smem + (s % 3) * SLAB;
     const size_t r0 = (size_t)rbeg + (size_t)s * kWideR;
+    if (JW == 4) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = wave + 4 * i;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(jb.A + (r0 + row) * jb.lda + 4 * lane), (lds_ptr_t)(buf + row * 256), 16, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        const int row = wave + 4 * i;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(jb.A + (r0 + row) * jb.lda + 4 * lane), (lds_ptr_t)(buf + row * AW), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int pair = wave + 4 * i;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(jb.A + (r0 + 2 * pair + (lane >> 5)) * jb.lda + 4 * (lane & 31)),
+                                         (lds_ptr_t)(buf + pair * 256), 16, 0, 0);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int pair = wave + 4 * i;
       __builtin_amdgcn_global_load_lds((glb_ptr_t)(jb.B + (r0 + 2 * pair + (lane >> 5)) * jb.ldb + 4 * (lane & 31)),
-                                       (lds_ptr_t)(buf + kWideR * 256 + pair * 256), 16, 0, 0);
+                                       (lds_ptr_t)(buf + kWideR * AW + pair * 256), 16, 0, 0);
     }
   };
   if (nslabs > 0) fetch(0);
   if (nslabs > 1) fetch(1);
   for (int s = 0; s < nslabs; ++s) {
-    // slab s has landed (this wave's share: all but the 6 loads of slab s + 1, if any), for every wave: barrier.  The
+    // slab s has landed (this wave's share: all but the loads of slab s + 1, if any), for every wave: barrier.  The
     // barrier also says every wave is done reading the buffer of slab s - 1, which slab s + 2 then overwrites.
-    if (s + 1 < nslabs) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (s + 1 < nslabs) {
+      if (JW == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     if (s + 2 < nslabs) fetch(s + 2);
-    const float* As = smem + (s % 3) * kWideSlab + 64 * wave + 4 * c;
-    const float* Bs = smem + (s % 3) * kWideSlab + kWideR * 256 + 4 * c;
+    const float* As = smem + (s % 3) * SLAB + 64 * jt + 4 * c;
+    const float* Bs = smem + (s % 3) * SLAB + kWideR * AW + 64 * kt0 + 4 * c;
 #pragma unroll
     for (int st = 0; st < kWideR / 4; ++st) {
-      const f32x4 va = *reinterpret_cast<const f32x4*>(As + (4 * st + q) * 256);
-      const f32x4 vb0 = *reinterpret_cast<const f32x4*>(Bs + (4 * st + q) * 128);
-      const f32x4 vb1 = *reinterpret_cast<const f32x4*>(Bs + (4 * st + q) * 128 + 64);
+      const f32x4 va = *reinterpret_cast<const f32x4*>(As + (4 * st + q) * AW);
+      f32x4 vb[NK];
+#pragma unroll
+      for (int k = 0; k < NK; ++k) vb[k] = *reinterpret_cast<const f32x4*>(Bs + (4 * st + q) * 128 + 64 * k);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        bs[u] += va[u];
+        if (kt0 == 0) bs[u] += va[u];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          acc[u][v] = mfma16(va[u], vb0[v], acc[u][v]);
-          acc[u][4 + v] = mfma16(va[u], vb1[v], acc[u][4 + v]);
-        }
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[u][4 * k + v] = mfma16(va[u], vb[k][v], acc[u][4 * k + v]);
       }
     }
   }
-  // C tile (u, v) of k-tile kt: the lane holds dW row j = 64 wave + 4 (4 q + i) + u, columns 64 kt + 4 c + v
+  // C tile (u, v) of column half k: the lane holds dW row j = 64 jt + 4 (4 q + i) + u, columns 64 (kt0 + k) + 4 c + v
 #pragma unroll
   for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float* d = slab + jb.dst_off + (size_t)(64 * wave + 4 * (4 * q + i) + u) * jb.dst_ld + 4 * c;
+      float* d = slab + jb.dst_off + (size_t)(64 * jt + 4 * (4 * q + i) + u) * jb.dst_ld + 64 * kt0 + 4 * c;
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-        *reinterpret_cast<f32x4*>(d + 64 * kt) = f32x4{acc[u][4 * kt][i], acc[u][4 * kt + 1][i], acc[u][4 * kt + 2][i], acc[u][4 * kt + 3][i]};
+      for (int k = 0; k < NK; ++k)
+        *reinterpret_cast<f32x4*>(d + 64 * k) = f32x4{acc[u][4 * k][i], acc[u][4 * k + 1][i], acc[u][4 * k + 2][i], acc[u][4 * k + 3][i]};
     }
-  if (jb.bias_off >= 0) {
+  if (jb.bias_off >= 0 && kt0 == 0) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       float sum = bs[u];
       sum += __shfl_xor(sum, 16, 64);
       sum += __shfl_xor(sum, 32, 64);
-      if (q == 0) slab[jb.bias_off + 64 * wave + 4 * c + u] = sum;
+      if (q == 0) slab[jb.bias_off + 64 * jt + 4 * c + u] = sum;
     }
   }
 }
@@ -1594,7 +1618,8 @@ __device__ __forceinline__ void wgrad_body(float* smem) {
 #else
   unsigned long long* wst = nullptr;
 #endif
-  if (WIDE && kind == WG_WIDE) wgrad_wide(jb, rbeg, rend, slab, smem);
+  if (WIDE && kind == WG_WIDE && jb.a_cols == 256) wgrad_wide<4>(jb, rbeg, rend, slab, smem);
+  else if (WIDE && kind == WG_WIDE) wgrad_wide<2>(jb, rbeg, rend, slab, smem);
   else if (kind == WG_FULL) wgrad_block<4, 4, WG_FULL>(jb, rbeg, rend, jrows - 1, slab, smem, wst);
   else if (kind == WG_SKINNY_B) wgrad_block<4, 1, WG_SKINNY_B>(jb, rbeg, rend, jrows - 1, slab, smem, wst);
   else wgrad_block<1, 4, WG_SKINNY_A>(jb, rbeg, rend, jrows - 1, slab, smem, wst);

@@ -9,8 +9,8 @@
 gfx950 correction (MI355X_MICROARCH.md, HBM/rocprofv3 section): FETCH_SIZE / WRITE_SIZE are KiB and FETCH_SIZE
 counts half of the wide coalesced reads, so HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
 
-k_wgrad and k_reduce_adam are each launched twice per step (the D instance first, then the G instance); they are
-split by dispatch order.
+k_wgrad (k_wgrad_wide at large M) and k_reduce_adam are each launched twice per step (the D instance first, then the G
+instance); they are split by dispatch order.
 """
 import csv
 import glob
@@ -33,7 +33,7 @@ def _rows(root, sql):
 def _label(name, seen):
     name = re.sub(r"\(.*$", "", name).replace("void ", "").strip()
     base = re.sub(r"<.*>$", "", name)
-    if base in ("ndp::k_wgrad", "ndp::k_reduce_adam"):
+    if base in ("ndp::k_wgrad", "ndp::k_wgrad_wide", "ndp::k_reduce_adam"):
         name = base
         seen[name] += 1
         name += "[D]" if seen[name] % 2 == 1 else "[G]"
