@@ -61,9 +61,13 @@ HBM_PEAK_GBS = 8000.0
 # gfx950 correction of MI355X_MICROARCH.md section HBM: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
 # bench.py cannot read PMC counters itself; the figure is reported only for the workload it was
 # measured on.
-PMC_HBM_BYTES_DEFAULT = {"k_phase_a": 25417552, "k_phase_b": 18646541, "k_wgrad[D]": 18800796,
-                         "k_wgrad[G]": 21490208}
-PMC_SOURCE = "profiles/r02_v13_pmc_hbm.csv (rocprofv3 --pmc, bytes per launch)"
+PMC_HBM_BYTES_DEFAULT = {"k_phase_a": 25417444, "k_phase_b": 18653715, "k_wgrad[D]": 18793628,
+                         "k_wgrad[G]": 22548836}
+PMC_SOURCE = "profiles/r03_final_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"
+# matrix-pipe utilisation of the same kernels from SQ counters (SQ_VALU_MFMA_BUSY_CYCLES over the launch's SIMD-cycles at
+# 2.4 GHz; profiles/README.md, round 3): reported beside the event-timed fraction, for the default workload only
+PMC_MFMA_BUSY_DEFAULT = {"k_phase_a": 0.2547, "k_phase_b": 0.2280, "k_wgrad[D]": 0.1402, "k_wgrad[G]": 0.1876}
+PMC_MFMA_SOURCE = "profiles/r03_cfg2_pmc_sq.csv (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ...; also wait / LDS / L2 shares)"
 
 # algorithmic MACs per M-row of each kernel (629,760 per row per step)
 G_FWD = 128 * 258 + 64 * 128 + 128 * 64 + 256 * 128 + 4 * 256           # 83,200
@@ -897,6 +901,8 @@ def main():
                      "frac_reference_equivalent": round(achieved * kernel_macs(1)[0][dom] / table[dom] / MFMA_F32_PEAK_TFLOPS, 4),
                      "traffic": PMC_HBM_BYTES_DEFAULT.get(dom) if (batch, k) == (64, 6) else None,
                      "traffic_source": PMC_SOURCE,
+                     "mfma_busy_counter": PMC_MFMA_BUSY_DEFAULT.get(dom) if (batch, k) == (64, 6) else None,
+                     "mfma_busy_source": PMC_MFMA_SOURCE,
                      "algorithmic_flops_per_launch": dom_flops,
                      "flops_note": "per-kernel figures count the MACs executed: D's real pass runs on the FLAT distinct "
                                    "rows (1/K of what the reference feeds through D, train_gan.py:140-156)",
