@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NDP_VERSION 134          /* 0.3.2: ndp_fm_* (forward / next-frame model), ndp_fm_backward, ndp_fm_side_stream */
+#define NDP_VERSION 135          /* 0.3.2: ndp_fm_* (forward / next-frame model), ndp_fm_backward, ndp_fm_side_stream */
 
 #define NDP_OK            0
 #define NDP_E_ARG         1      /* bad argument (shape, alignment, null) */
@@ -373,6 +373,19 @@ int ndp_fm_train_grads_u8(const float *params, float *running_stats, const uint8
                           float *grad, float *loss, float *loss_sum, float *resid_out,
                           float *workspace, void *stream);
 int ndp_fm_side_stream(int on);
+/* Cross-rank BatchNorm statistics for a data-parallel driver.  The per-channel sums a BatchNorm needs are accumulated
+ * by the kernel that produces its input as 64-bit fixed-point integers (csrc/ndp_forward_model.inc, "epilogue
+ * statistics").  With a function set here, every ndp_fm_forward(training) / ndp_fm_train_grads / ndp_fm_backward call
+ * invokes fn(acc, words, stream, ctx) on the calling thread between the launch that fills an accumulator and the launch
+ * that reads it; fn must enqueue, on `stream`, an in-place SUM over the ranks of the `words` int64 values at `acc` (device
+ * memory inside the workspace) -- an RCCL all-reduce of ncclInt64.  Integer sums are exact and order-free: `world` ranks
+ * with B / world images each then normalise, and update the running statistics, exactly as one process with B images
+ * does (the reference trains on one device: train_forward_model.py:62); the BatchNorm weight / bias gradients stay each
+ * rank's own share, for the gradient all-reduce to add up.  20 small collectives per iteration.  fn == NULL: off (per-rank
+ * statistics, what torch's DistributedDataParallel does without SyncBatchNorm).  Process-wide. */
+typedef void (*ndp_fm_stat_sync_fn)(void *acc, int64_t words, void *stream, void *ctx);
+int ndp_fm_set_stat_sync(ndp_fm_stat_sync_fn fn, void *ctx, int world);
+
 /* Gradient buckets for a data-parallel driver (the reference trains on one device: train_forward_model.py:62; the
  * north star asks for the all-reduce of the gradients "overlapped with backward").  ndp_fm_grad_buckets writes the 7
  * ranges (offset, count: floats of the flat gradient) in the order in which a backward pass completes them -- the weight

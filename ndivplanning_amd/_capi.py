@@ -17,7 +17,7 @@ ACTION_DIM = 4
 MAX_NOISE_DIM = 16
 MAX_SAMPLES = 256
 ROW_PAD = 32
-EXPECTED_VERSION = 134          # NDP_VERSION of include/ndp.h this binding was written against
+EXPECTED_VERSION = 135          # NDP_VERSION of include/ndp.h this binding was written against
 
 _lib = None
 
@@ -114,6 +114,7 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_void_p]),
     "ndp_fm_side_stream": (c_int, [c_int]),
     "ndp_fm_grad_buckets": (c_int, [POINTER(c_int64), POINTER(c_int64), c_int]),
+    "ndp_fm_set_stat_sync": (c_int, [c_void_p, c_void_p, c_int]),
     "ndp_fm_bucket_wait": (c_int, [c_int, c_void_p]),
     "ndp_fm_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "ndp_fm_apply_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
@@ -226,3 +227,6 @@ def fm_grad_buckets():
         msg = lib.ndp_last_error()
         raise NdpError("ndp_fm_grad_buckets failed: %s" % (msg.decode() if msg else "?"))
     return [(int(off[i]), int(cnt[i])) for i in range(n)]
+
+
+STAT_SYNC_FN = ctypes.CFUNCTYPE(None, c_void_p, c_int64, c_void_p, c_void_p)    # ndp_fm_stat_sync_fn (include/ndp.h)

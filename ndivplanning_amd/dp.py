@@ -139,6 +139,50 @@ class BucketedMeanAllReduce:
         main.wait_stream(self.stream)
 
 
+class CrossRankBatchNorm:
+    """Forward-model BatchNorm statistics over ALL ranks' images (include/ndp.h, ndp_fm_set_stat_sync): the library calls
+    back between the launch that fills a BatchNorm's fixed-point accumulator and the launch that reads it, and this
+    all-reduces (SUM, int64: exact, order-free) the accumulator in place on the launch stream.  W ranks with B / W images
+    each then train exactly the single-process step on B images (up to fp32 summation order inside a tile): what the
+    reference's `batch_size` means.  20 small collectives per iteration, on the critical path.
+
+    `workspace`: the trainer's workspace tensor (the accumulators live inside it).  Process-wide while installed;
+    `close()` (or a new instance) removes it.  An exception inside a callback is kept and re-raised by `check()`."""
+
+    def __init__(self, workspace, world, group=None):
+        from . import _capi
+        self._capi, self.lib = _capi, _capi.load()
+        self.workspace, self.world, self.group = workspace, int(world), group
+        self.error = None
+        self.calls = 0
+
+        def sync(acc, words, stream, ctx):
+            try:
+                off = (int(acc) - self.workspace.data_ptr()) // 4
+                if off < 0 or off + 2 * int(words) > self.workspace.numel() or (int(acc) - self.workspace.data_ptr()) % 8:
+                    raise RuntimeError("statistics accumulator outside the workspace")
+                view = self.workspace[off:off + 2 * int(words)].view(torch.int64)
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                self.calls += 1
+            except Exception as exc:                           # noqa: BLE001 - must not propagate through the C frame
+                if self.error is None:
+                    self.error = exc
+        self._cb = _capi.STAT_SYNC_FN(sync)                    # keep the thunk alive as long as it is installed
+        import ctypes
+        _capi.check(self.lib.ndp_fm_set_stat_sync(ctypes.cast(self._cb, ctypes.c_void_p), None, self.world),
+                    "ndp_fm_set_stat_sync")
+
+    def check(self):
+        if self.error is not None:
+            err, self.error = self.error, None
+            raise RuntimeError("cross-rank BatchNorm statistics: %r" % (err,))
+
+    def close(self):
+        if self._cb is not None:
+            self.lib.ndp_fm_set_stat_sync(None, None, 1)
+            self._cb = None
+
+
 def run_step(backend, reduce_fn, discrim_steps=1):
     """One training iteration in data-parallel order.  `backend` provides
     d_grads(first) -> flat D gradient, apply_d(grad), g_grads() -> flat G gradient, apply_g(grad)."""

@@ -20,7 +20,7 @@ from .models import forward_encoder as FE
 
 class ForwardModelTrainer:
     def __init__(self, model: FE.ForwardAutoencoder, batch: int, lr: float = 2e-4, betas=(0.5, 0.999), eps: float = 1e-8,
-                 reduce_fn=None, keep_residual: bool = False, bucket_reduce=None):
+                 reduce_fn=None, keep_residual: bool = False, bucket_reduce=None, sync_batchnorm_world: int = 1):
         self.lib = _capi.load()
         self.model = model
         dev = next(model.parameters()).device
@@ -41,6 +41,11 @@ class ForwardModelTrainer:
         self.resid = torch.zeros(self.batch, 3, 128, 128, **f32) if keep_residual else None
         self.workspace = torch.empty(self.lib.ndp_fm_workspace_floats(self.batch), **f32)
         self.steps = 0
+        # BatchNorm statistics over all ranks' images (dp.CrossRankBatchNorm): W ranks x B / W images = one process x B
+        self.stat_sync = None
+        if int(sync_batchnorm_world) > 1:
+            from . import dp
+            self.stat_sync = dp.CrossRankBatchNorm(self.workspace, int(sync_batchnorm_world))
         with torch.cuda.device(dev):
             _capi.check(self.lib.ndp_fm_pack_params(_capi.ptr(self.params), _capi.ptr(self.workspace),
                                                     _capi.stream_ptr(dev)), "ndp_fm_pack_params")
@@ -69,6 +74,8 @@ class ForwardModelTrainer:
             _capi.check(fn(p(self.params), p(self.stats), p(state_cur), p(state_fut), p(actions), n,
                            p(self.grad), p(self.loss), p(self.loss_sum), p(self.resid) if self.resid is not None else None,
                            p(self.workspace), _capi.stream_ptr(self.device)), name)
+        if self.stat_sync is not None:
+            self.stat_sync.check()
         return self.loss
 
     def apply(self):
@@ -89,6 +96,12 @@ class ForwardModelTrainer:
             self.reduce_fn(self.grad)
         self.apply()
         return self.loss
+
+    def close(self):
+        """Remove the process-wide cross-rank statistics hook this trainer installed (if any)."""
+        if self.stat_sync is not None:
+            self.stat_sync.close()
+            self.stat_sync = None
 
     def gradient_buckets(self):
         """[(offset, count)] of the flat gradient, in the order the backward pass completes them."""

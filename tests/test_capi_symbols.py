@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_host_only_entry_points(lib):
     from ndivplanning_amd import _capi
-    assert lib.ndp_version() == _capi.EXPECTED_VERSION == 134
+    assert lib.ndp_version() == _capi.EXPECTED_VERSION == 135
     assert lib.ndp_g_param_count(2) == 83780
     assert lib.ndp_d_param_count() == 58305           # row a4
     assert lib.ndp_g_param_count(16) == 83780 + 128 * 14

@@ -374,7 +374,7 @@ def test_two_ranks_on_one_gpu_average_their_gradients(tmp_path):
     cfg = {"random_seed": 0, "train_data_path": "synthetic:4:images", "gpu_id": 0, "trajectory_length": 3,
            "forward_save_path": str(tmp_path / "fm"),
            "training": {"forward": {"num_epochs": 1, "learning_rate": LR, "report_feq": 10, "batch_size": 4,
-                                    "epochs_per_stage": 1, "step_lr_gamma": 0.1}}}
+                                    "epochs_per_stage": 1, "step_lr_gamma": 0.1, "sync_batchnorm": False}}}
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -432,6 +432,44 @@ def test_two_ranks_on_one_gpu_average_their_gradients(tmp_path):
     mp.spawn(_fm_rank_main, args=(2, port, cfg, str(single_dir)), nprocs=2, join=True)
     single = torch.load(str(single_dir / "fm_rank0.pt"))
     assert torch.equal(single["params"], res[0]["params"]) and single["hist"] == res[0]["hist"]
+
+
+def test_two_ranks_with_cross_rank_batchnorm_train_the_single_process_step(tmp_path):
+    """`batch_size` is the global batch.  Two ranks with 2 images each, BatchNorm statistics summed over the ranks (the
+    fixed-point accumulators all-reduced as int64: exact, order-free) and gradients averaged, against ONE process on the
+    same 4 images per step: the same losses, the same running statistics on every rank, the same parameters -- up to the
+    fp32 summation order inside a tile and Adam's +-lr on the biases whose gradient is rounding noise."""
+    import socket
+    import torch.multiprocessing as mp
+    from ndivplanning_amd import train_forward_model as script
+    from ndivplanning_amd.utils.file import AttrDict
+    cfg = {"random_seed": 0, "train_data_path": "synthetic:4:images", "gpu_id": 0, "trajectory_length": 3,
+           "forward_save_path": str(tmp_path / "fm"),
+           "training": {"forward": {"num_epochs": 1, "learning_rate": LR, "report_feq": 10, "batch_size": 4,
+                                    "epochs_per_stage": 1, "step_lr_gamma": 0.1}}}       # sync_batchnorm: the default
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_fm_rank_main, args=(2, port, cfg, str(tmp_path)), nprocs=2, join=True)
+    res = [torch.load(str(tmp_path / ("fm_rank%d.pt" % r))) for r in range(2)]
+    assert torch.equal(res[0]["params"], res[1]["params"])                 # replicas in lockstep
+    assert torch.equal(res[0]["stats"], res[1]["stats"])                   # ... running statistics included: they are global
+    # the same epoch in this process, alone, on the whole batch
+    single_cfg = AttrDict(cfg)
+    single_cfg["forward_save_path"] = str(tmp_path / "single")
+    hist = script.train(single_cfg)
+    tr = script.train.last_trainer
+    assert abs(hist[0] - res[0]["hist"][0]) <= 2e-6 * max(1.0, abs(hist[0]))
+    stats = tr.stats.cpu()
+    assert float((stats - res[0]["stats"]).abs().max()) <= 1e-5 * float(stats.abs().max())
+    mine = {k: v.cpu() for k, v in tr.named_parameters().items()}
+    worst = 0.0
+    for name, want in mine.items():
+        if name in NOISE_BIASES:
+            continue
+        worst = max(worst, float((res[0]["named"][name] - want).abs().max()))
+    # two Adam steps of lr 2e-4: identical gradients give identical steps; a differing sign would show as 2 lr = 4e-4
+    assert worst <= 2e-5, worst
 
 
 def test_gradient_buckets_cover_the_flat_vector_in_completion_order():
