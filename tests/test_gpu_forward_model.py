@@ -460,16 +460,74 @@ def test_two_ranks_with_cross_rank_batchnorm_train_the_single_process_step(tmp_p
     hist = script.train(single_cfg)
     tr = script.train.last_trainer
     assert abs(hist[0] - res[0]["hist"][0]) <= 2e-6 * max(1.0, abs(hist[0]))
+    # (a tile's fp32 column sum groups its rows differently when the tile holds one rank's images or both ranks': 1e-7 of
+    # sum x^2, which var = E[x^2] - mean^2 amplifies where a channel's mean dominates its spread: measured 3e-5)
     stats = tr.stats.cpu()
-    assert float((stats - res[0]["stats"]).abs().max()) <= 1e-5 * float(stats.abs().max())
+    assert float((stats - res[0]["stats"]).abs().max()) <= 1e-4 * float(stats.abs().max())
     mine = {k: v.cpu() for k, v in tr.named_parameters().items()}
-    worst = 0.0
+    worst, off, total = 0.0, 0, 0
     for name, want in mine.items():
         if name in NOISE_BIASES:
             continue
-        worst = max(worst, float((res[0]["named"][name] - want).abs().max()))
-    # two Adam steps of lr 2e-4: identical gradients give identical steps; a differing sign would show as 2 lr = 4e-4
-    assert worst <= 2e-5, worst
+        diff = (res[0]["named"][name] - want).abs()
+        worst = max(worst, float(diff.max()))
+        off += int((diff > 2e-5).sum())
+        total += diff.numel()
+    # two Adam steps of lr 2e-4: the gradients agree to ~1e-5 of their tensor's norm (next test), but Adam's first steps
+    # are lr * sign(g) whatever |g| is, and in a network this sparse ~1 % of the 33 M elements have a gradient inside that
+    # noise and may step the other way, 2 lr = 4e-4 apart (measured: 1.1 %)
+    assert worst <= 2.5 * 2 * LR and off <= 0.05 * total, (worst, off, total)
+
+
+def _syncbn_rank(rank, world, port, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      NDP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from ndivplanning_amd import dp
+    dp.init_process_group(DEV)
+    tr, _ = _hip_trainer(3, 2, sync_batchnorm_world=world)
+    frames, actions = _inputs(7, 4)
+    sl = slice(2 * rank, 2 * rank + 2)
+    tr.grads(frames[sl, 0].contiguous().to(DEV), frames[sl, 1].contiguous().to(DEV), actions[sl, 0].contiguous().to(DEV))
+    g = tr.grad.clone()
+    dp.mean_all_reduce(world)(g)
+    torch.save({"grad": g.cpu(), "loss": tr.loss.item(), "stats": tr.stats.cpu(), "calls": tr.stat_sync.calls},
+               os.path.join(out_dir, "syncbn%d.pt" % rank))
+    tr.close()
+    dist.destroy_process_group()
+
+
+def test_cross_rank_batchnorm_gives_the_global_batch_gradient(tmp_path):
+    """ndp_fm_set_stat_sync / dp.CrossRankBatchNorm at the gradient level: two ranks with 2 images each -- every BatchNorm's
+    fixed-point accumulator all-reduced as int64 between the kernel that fills it and the kernel that reads it (10 forward
+    + 10 backward callbacks per rank), d beta / d gamma from each rank's own sums, dx from the global ones -- then the mean
+    of the two flat gradients, against ONE process on the 4 images: same loss, same running statistics, every gradient
+    tensor within 1e-4 of its norm (measured 2e-7 ... 3e-5; the biases in front of a BatchNorm are rounding noise)."""
+    import socket
+    import torch.multiprocessing as mp
+    from ndivplanning_amd.models import forward_encoder as FE
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_syncbn_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    res = [torch.load(str(tmp_path / ("syncbn%d.pt" % r))) for r in range(2)]
+    assert res[0]["calls"] == res[1]["calls"] == 20
+    tr, _ = _hip_trainer(3, 4)
+    frames, actions = _inputs(7, 4)
+    tr.grads(frames[:, 0].contiguous().to(DEV), frames[:, 1].contiguous().to(DEV), actions[:, 0].contiguous().to(DEV))
+    assert abs(tr.loss.item() - (res[0]["loss"] + res[1]["loss"]) / 2) <= 1e-6
+    assert abs(res[0]["loss"] - res[1]["loss"]) > 1e-4                    # (the ranks did see different images)
+    assert torch.equal(res[0]["stats"], res[1]["stats"])
+    assert float((tr.stats.cpu() - res[0]["stats"]).abs().max()) <= 1e-5
+    want = FE.unpack_vector(tr.grad, tr.model)
+    got = FE.unpack_vector(res[0]["grad"].to(DEV), tr.model)
+    for name in want:
+        if name in NOISE_BIASES:
+            continue
+        assert _rel(got[name], want[name]) <= 1e-4, (name, _rel(got[name], want[name]))
 
 
 def test_gradient_buckets_cover_the_flat_vector_in_completion_order():
