@@ -829,7 +829,9 @@ def main():
                     model.decoder.weight_init(0.0, 0.02)
                     model.encoder.weight_init(0.0, 0.02)
                     kw = {"single": dict(reduce_fn=b.dp.mean_all_reduce(world)),
-                          "bucketed": dict(bucket_reduce=b.dp.BucketedMeanAllReduce(world)), "none": {}}[kind]
+                          "bucketed": dict(bucket_reduce=b.dp.BucketedMeanAllReduce(world)),
+                          "bucketed_cross_rank_batchnorm": dict(bucket_reduce=b.dp.BucketedMeanAllReduce(world),
+                                                                sync_batchnorm_world=world), "none": {}}[kind]
                     t_ = ForwardModelTrainer(model.to(dev).train(), batch=n_, **kw)
                     for _ in range(3):
                         t_.step(cur, fut, act)
@@ -841,20 +843,23 @@ def main():
                     sec_ = b.max_over_ranks(time.perf_counter() - t0)
                     same = b.dp.replicas_bit_identical([t_.params]) if kind != "none" else None
                     mb = t_.grad.numel() * 4 / 1e6
+                    t_.close()
                     del t_, model
                     torch.cuda.empty_cache()
                     return 1e3 * sec_ / steps_, same, mb
                 base_ms, _, mb = run("none")
                 out_ = {"workload": "train_forward_model.py iteration, 8 images per rank, mean all-reduce of the flat gradient "
                                     "(%.0f MB)" % mb, "scaling": "weak", "ms_per_step_without_exchange": round(base_ms, 4)}
-                for kind in ("bucketed", "single"):
+                for kind in ("bucketed", "single", "bucketed_cross_rank_batchnorm"):
                     ms_, same, _ = run(kind)
                     out_[kind] = {"ms_per_step": round(ms_, 4), "global_images_per_sec": round(n_ * world * 1e3 / ms_, 1),
                                   "exposed_all_reduce_ms": round(ms_ - base_ms, 4), "replicas_bit_identical": same}
                 out_["replicas_bit_identical"] = bool(out_["bucketed"]["replicas_bit_identical"] and out_["single"]["replicas_bit_identical"])
                 out_["how"] = ("bucketed: 7 ranges of the flat gradient, each all-reduced on a communication stream as soon as the "
                                "backward pass has completed it (ndp_fm_grad_buckets / ndp_fm_bucket_wait); single: one "
-                               "collective between backward and Adam")
+                               "collective between backward and Adam; bucketed_cross_rank_batchnorm: plus the BatchNorm statistics "
+                               "summed over the ranks (20 int64 all-reduces per iteration, ndp_fm_set_stat_sync): the ranks train "
+                               "the single-process step on the global batch -- train_forward_model.py's default")
                 return out_
             extra("forward_model_dp", forward_model_dp)
         else:
