@@ -61,8 +61,8 @@ HBM_PEAK_GBS = 8000.0
 # gfx950 correction of MI355X_MICROARCH.md section HBM: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
 # bench.py cannot read PMC counters itself; the figure is reported only for the workload it was
 # measured on.
-PMC_HBM_BYTES_DEFAULT = {"k_phase_a": 25417444, "k_phase_b": 18653715, "k_wgrad[D]": 18793628,
-                         "k_wgrad[G]": 22548836}
+PMC_HBM_BYTES_DEFAULT = {"k_phase_a": 25417455, "k_phase_b": 18645523, "k_wgrad[D]": 18803484,
+                         "k_wgrad[G]": 22566634}
 PMC_SOURCE = "profiles/r03_final_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"
 # matrix-pipe utilisation of the same kernels from SQ counters (SQ_VALU_MFMA_BUSY_CYCLES over the launch's SIMD-cycles at
 # 2.4 GHz; profiles/README.md, round 3): reported beside the event-timed fraction, for the default workload only
