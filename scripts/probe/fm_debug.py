@@ -52,9 +52,9 @@ tr.grads(cur.to(dev), fut.to(dev), act.to(dev))
 torch.cuda.synchronize()
 print("hip    loss %.8f" % tr.loss.item())
 lib = _capi.load()
-names = ["IMG32", "CAT6", "CAT5", "CAT4", "CAT3", "CAT2", "Z", "RAW1", "RAW2", "RAW3", "RAWU1", "RAWU2", "RAWU3", "RAWU4",
+names = ["COLS", "CAT6", "CAT5", "CAT4", "CAT3", "CAT2", "Z", "RAW1", "RAW2", "RAW3", "RAWU1", "RAWU2", "RAWU3", "RAWU4",
          "RAWU5", "RAWU6", "UP6", "RAWR1", "R1", "Y2", "DCAT6", "DCAT5", "DCAT4", "DCAT3", "DCAT2", "DZ", "DUP6", "DR1"]
-shape = {"IMG32": (128, 32), "CAT6": (64, 128), "CAT5": (32, 256), "CAT4": (16, 512), "CAT3": (8, 1024), "CAT2": (4, 2048),
+shape = {"COLS": (64, 32), "CAT6": (64, 128), "CAT5": (32, 256), "CAT4": (16, 512), "CAT3": (8, 1024), "CAT2": (4, 2048),
          "RAW1": (64, 64), "RAW2": (32, 128), "RAW3": (16, 256), "RAWU1": (4, 1024), "RAWU2": (8, 512), "RAWU3": (16, 256),
          "RAWU4": (32, 128), "RAWU5": (64, 64), "RAWU6": (128, 32), "UP6": (128, 32), "RAWR1": (128, 32), "R1": (128, 32),
          "Y2": (128, 4), "DCAT6": (64, 128), "DCAT5": (32, 256), "DCAT4": (16, 512), "DCAT3": (8, 1024), "DCAT2": (4, 2048),
