@@ -111,7 +111,7 @@ class ForwardModelTrainer:
     _MAPS = {"feat1": (1, 64, 128, 64, 128), "up5": (1, 64, 128, 0, 64), "feat2": (2, 32, 256, 128, 256), "up4": (2, 32, 256, 0, 128),
              "feat3": (3, 16, 512, 256, 512), "up3": (3, 16, 512, 0, 256), "feat4": (4, 8, 1024, 512, 1024),
              "up2": (4, 8, 1024, 0, 512), "feat5": (5, 4, 2048, 1024, 2048), "up1": (5, 4, 2048, 0, 1024),
-             "up6": (16, 128, 32, 0, 32), "r1": (18, 128, 32, 0, 16)}
+             "up6": (16, 128, 32, 0, 32), "r1": (18, 128, 16, 0, 16)}
 
     def activation(self, name, n):
         """Post-ReLU map `name` (feat1..5, up1..6, r1) of the last call on n images, NCHW."""
