@@ -689,3 +689,30 @@ def test_byte_frames_train_exactly_as_the_floats_the_reference_would_upload():
         y8 = model(frames[:, 0].contiguous().to(DEV), actions[:, 0].contiguous().to(DEV))
         yf = model(floats[:, 0].contiguous().to(DEV), actions[:, 0].contiguous().to(DEV))
     assert y8.shape == (3, 3, 128, 128) and torch.equal(y8, yf)
+
+
+def test_the_optimizer_launch_leaves_the_second_weight_order_a_full_repack_would():
+    """ndp_fm_apply_adam writes the new weights in both orders in one launch (k_fm_adam_pack: 32 x 32 tiles transposed
+    through LDS, conv1's compact [64][32] copy and the refinement layers' [ci][tap][co] copies written element by element).
+    ndp_fm_pack_params rebuilds the second order from the parameters alone: after two training steps it must change
+    nothing -- the fixed head of the workspace (second weight order + statistics scratch) stays bit-identical."""
+    from ndivplanning_amd import _capi
+    n = 3
+    tr, _ = _hip_trainer(5, n)
+    frames, actions = _inputs(9, n)
+    cur, fut, act = (t.contiguous().to(DEV) for t in (frames[:, 0], frames[:, 1], actions[:, 0]))
+    for _ in range(2):
+        tr.step(cur, fut, act)
+    torch.cuda.synchronize()
+    head = tr.lib.ndp_fm_workspace_offset(n, 0)
+    assert head > 30_000_000                                       # the second order of 33 M weights lives there
+    before = tr.workspace[:head].view(torch.int32).clone()         # bits: the scratch words behind the weights may hold anything
+    _capi.check(tr.lib.ndp_fm_pack_params(_capi.ptr(tr.params), _capi.ptr(tr.workspace), _capi.stream_ptr(DEV)),
+                "ndp_fm_pack_params")
+    torch.cuda.synchronize()
+    assert torch.equal(before, tr.workspace[:head].view(torch.int32))
+    # and the copy is in use: a forward pass right after the repack gives the same loss as one before it
+    tr.grads(cur, fut, act)
+    loss_a = tr.loss.item()
+    tr.grads(cur, fut, act)
+    assert tr.loss.item() == loss_a
