@@ -143,7 +143,7 @@ def _rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("n", [1, 3, 8, 16])      # (16: from there deconv5 runs its four parity classes in one workgroup)
+@pytest.mark.parametrize("n", [1, 3, 8, 16, 32])  # (from 16: deconv5 runs its four parity classes in one workgroup; 32: the bench size, unsplit data gradients)
 def test_training_iterations_against_the_oracle_elementwise(n):
     """Every gradient of two iterations against the oracle, adjudicated by the oracle's own arithmetic in fp64: the error of
     the kernels against fp64 may be at most twice the fp32 oracle's (or 2e-5).  Two things keep the comparison tight:
